@@ -1,0 +1,1460 @@
+/*
+ * oracle/cpu_ref.c — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * A literal CPU restatement (plain C, f32, recursive, brute force, full sorted
+ * intersection list, per-test matrix inverse) of the reference's hot path
+ * `Camera.render -> World.colorAt` (arieldon/ray-tracer @ v1).  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this; the
+ * product library never links or calls it.
+ *
+ * The reference is Zig 0.9-dialect source and no Zig toolchain exists in this
+ * image, so the reference itself cannot be compiled or run.
+ * Pinning: this restatement is checked against the golden images the reference
+ * ships that v1 reproduces (samples/images/skewed_triangle.ppm, cone.ppm, and
+ * cylinder_world.ppm outside the glass cylinder's footprint) and against the 69
+ * known-answer tests in src/tuple.zig, src/matrix.zig, src/bounds.zig — see
+ * tests/test_oracle_golden.py and tests/test_math_kat.py.  Nothing in the
+ * reference pins refraction / Schlick / n1-n2 at v1: "parity unpinned" for
+ * refractedColor, schlick and prepareComputationsForRefraction (they follow the
+ * v1 source text literally).
+ *
+ * Third-party arithmetic not vendored in /root/reference: Zig's std.math.pow /
+ * tan and the LLVM @sin/@cos lowering (Zig std lib 0.9.x, version unpinned — no
+ * build.zig.zon).  Zig 0.9's std.math.{pow,sin,cos,tan} are ports of Go's
+ * math.Pow and the Cephes sinf/cosf/tanf kernels; they are restated below from
+ * their published algorithms (zig_pow/zig_sin/zig_cos/zig_tan).  glibc's
+ * powf/sinf/cosf/tanf are selectable instead (oracle_set_libm) so that the
+ * golden-image tests can show which reading reproduces the shipped renders.
+ *
+ * Compile with: gcc -O2 -ffp-contract=off (no -ffast-math); explicit fmaf only
+ * at the reference's @mulAdd sites (src/cylinder.zig:40,45,98,99,
+ * src/cone.zig:53,58,111,112).
+ *
+ * Every function cites the reference file:line it follows.
+ */
+#include <math.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/rt_scene.h"
+
+#define EXPORT __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------ options */
+
+/* 0 = glibc libm, 1 = Zig 0.9 std.math restatement (default). */
+static int g_libm = 1;
+/* 0 = v1-literal n1/n2 container walk (std.meta.eql compares t too),
+ * 1 = "book" walk (compare shapes only) — secondary, for the stale goldens. */
+static int g_containers_book = 0;
+
+EXPORT void oracle_set_libm(int mode) { g_libm = mode; }
+EXPORT void oracle_set_containers(int book) { g_containers_book = book; }
+
+/* ------------------------------------------------------------- tuple.zig */
+
+typedef struct { float v[4]; } tuple;
+typedef struct { float c[3]; } color;
+
+static const float epsilon = 0.00001f; /* src/tuple.zig:10 */
+
+static tuple tup4(float x, float y, float z, float w) { tuple t = {{x, y, z, w}}; return t; }
+static tuple point(float x, float y, float z) { return tup4(x, y, z, 1.0f); }   /* tuple.zig:16 */
+static tuple vector(float x, float y, float z) { return tup4(x, y, z, 0.0f); }  /* tuple.zig:20 */
+
+static tuple tadd(tuple a, tuple b) { return tup4(a.v[0] + b.v[0], a.v[1] + b.v[1], a.v[2] + b.v[2], a.v[3] + b.v[3]); }
+static tuple tsub(tuple a, tuple b) { return tup4(a.v[0] - b.v[0], a.v[1] - b.v[1], a.v[2] - b.v[2], a.v[3] - b.v[3]); }
+static tuple tmuls(tuple a, float s) { return tup4(a.v[0] * s, a.v[1] * s, a.v[2] * s, a.v[3] * s); }
+static tuple tdivs(tuple a, float s) { return tup4(a.v[0] / s, a.v[1] / s, a.v[2] / s, a.v[3] / s); }
+static tuple tneg(tuple a) { return tup4(-a.v[0], -a.v[1], -a.v[2], -a.v[3]); }
+
+/* tuple.zig:38-40 — all four lanes, left to right. */
+static float dot(tuple u, tuple v) {
+    return u.v[0] * v.v[0] + u.v[1] * v.v[1] + u.v[2] * v.v[2] + u.v[3] * v.v[3];
+}
+
+/* tuple.zig:42-48 — only three lanes are initialised; the golden
+ * skewed_triangle.ppm is reproduced with w = 0. */
+static tuple cross(tuple u, tuple v) {
+    return tup4(u.v[1] * v.v[2] - u.v[2] * v.v[1],
+                u.v[2] * v.v[0] - u.v[0] * v.v[2],
+                u.v[0] * v.v[1] - u.v[1] * v.v[0],
+                0.0f);
+}
+
+static float magnitude(tuple v) { return sqrtf(dot(v, v)); }        /* tuple.zig:50-52 */
+static tuple normalize(tuple v) { return tdivs(v, magnitude(v)); }  /* tuple.zig:54-56 */
+
+/* tuple.zig:58-77 */
+static tuple reflect(tuple incident, tuple normal) {
+    tuple orthogonal_component = tmuls(normal, dot(incident, normal));
+    return tsub(incident, tmuls(orthogonal_component, 2.0f));
+}
+
+/* tuple.zig:32-36 */
+static int tup_equal(tuple a, tuple b) {
+    for (int i = 0; i < 4; ++i)
+        if (!(fabsf(a.v[i] - b.v[i]) <= epsilon)) return 0;
+    return 1;
+}
+
+/* ------------------------------------------------------------ matrix.zig */
+
+typedef rt_mat4 mat4;
+
+static const mat4 identity = {{{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}}};
+
+/* matrix.zig:43-60 */
+static mat4 mul_matrix(mat4 a, mat4 b) {
+    mat4 c;
+    for (int row = 0; row < 4; ++row)
+        for (int col = 0; col < 4; ++col)
+            c.m[row][col] = a.m[row][0] * b.m[0][col] +
+                            a.m[row][1] * b.m[1][col] +
+                            a.m[row][2] * b.m[2][col] +
+                            a.m[row][3] * b.m[3][col];
+    return c;
+}
+
+static tuple mrow(mat4 a, int r) { return tup4(a.m[r][0], a.m[r][1], a.m[r][2], a.m[r][3]); }
+
+/* matrix.zig:62-64 */
+static tuple mul_tuple(mat4 a, tuple b) {
+    return tup4(dot(mrow(a, 0), b), dot(mrow(a, 1), b), dot(mrow(a, 2), b), dot(mrow(a, 3), b));
+}
+
+/* matrix.zig:74-87 */
+static mat4 transpose(mat4 m) {
+    mat4 n;
+    for (int row = 0; row < 4; ++row)
+        for (int col = 0; col < 4; ++col) n.m[row][col] = m.m[col][row];
+    return n;
+}
+
+/* matrix.zig:89-147 — generic over 2x2/3x3/4x4; n is the dimension. */
+typedef struct { float m[4][4]; int n; } matn;
+
+static float determinant_n(matn m);
+
+static matn submatrix_n(matn m, int row, int col) { /* matrix.zig:109-127 */
+    matn r;
+    r.n = m.n - 1;
+    int y = 0;
+    for (int j = 0; j < m.n; ++j) {
+        if (j == row) continue;
+        int x = 0;
+        for (int i = 0; i < m.n; ++i) {
+            if (i == col) continue;
+            r.m[y][x] = m.m[j][i];
+            x += 1;
+        }
+        y += 1;
+    }
+    return r;
+}
+
+static float minor_n(matn m, int row, int col) { return determinant_n(submatrix_n(m, row, col)); } /* :137-139 */
+
+static float cofactor_n(matn m, int row, int col) { /* matrix.zig:141-147 */
+    if ((row + col) % 2 == 0) return minor_n(m, row, col);
+    return -minor_n(m, row, col);
+}
+
+static float determinant_n(matn m) { /* matrix.zig:89-107 */
+    float det = 0;
+    if (m.n == 2) {
+        det = m.m[0][0] * m.m[1][1] - m.m[0][1] * m.m[1][0];
+    } else {
+        for (int col = 0; col < m.n; ++col) det += m.m[0][col] * cofactor_n(m, 0, col);
+    }
+    return det;
+}
+
+static matn to_matn(mat4 a) {
+    matn r;
+    memcpy(r.m, a.m, sizeof r.m);
+    r.n = 4;
+    return r;
+}
+
+static float determinant_literal(mat4 a) { return determinant_n(to_matn(a)); }
+
+/* matrix.zig:153-168, literal: each element divides by a freshly computed
+ * determinant.  Kept for the self-check in tests/test_oracle_golden.py. */
+static mat4 inverse_literal(mat4 a) {
+    matn m = to_matn(a);
+    mat4 n;
+    for (int row = 0; row < 4; ++row)
+        for (int col = 0; col < 4; ++col) {
+            float c = cofactor_n(m, row, col);
+            n.m[col][row] = c / determinant_n(m);
+        }
+    return n;
+}
+
+/* The same arithmetic with the generic recursion unrolled: identical operations
+ * in identical order (first-row cofactor expansion accumulating from 0,
+ * matrix.zig:97-106), so the results are bit-identical to the literal form;
+ * determinant(m) is deterministic, so computing it once instead of 16 times
+ * changes nothing.  This is only to keep the oracle's run time usable. */
+static inline float det2(float a, float b, float c, float d) { return a * d - b * c; }
+
+static inline float det3(float m00, float m01, float m02, float m10, float m11, float m12,
+                         float m20, float m21, float m22) {
+    float det = 0;
+    det += m00 * det2(m11, m12, m21, m22);
+    det += m01 * -det2(m10, m12, m20, m22);
+    det += m02 * det2(m10, m11, m20, m21);
+    return det;
+}
+
+static float minor4(const mat4* a, int row, int col) {
+    float s[3][3];
+    int y = 0;
+    for (int j = 0; j < 4; ++j) {
+        if (j == row) continue;
+        int x = 0;
+        for (int i = 0; i < 4; ++i) {
+            if (i == col) continue;
+            s[y][x++] = a->m[j][i];
+        }
+        ++y;
+    }
+    return det3(s[0][0], s[0][1], s[0][2], s[1][0], s[1][1], s[1][2], s[2][0], s[2][1], s[2][2]);
+}
+
+static float cofactor4(const mat4* a, int row, int col) {
+    float m = minor4(a, row, col);
+    return ((row + col) % 2 == 0) ? m : -m;
+}
+
+static float determinant(mat4 a) {
+    float det = 0;
+    for (int col = 0; col < 4; ++col) det += a.m[0][col] * cofactor4(&a, 0, col);
+    return det;
+}
+
+static mat4 inverse(mat4 a) {
+    mat4 n;
+    const float det = determinant(a);
+    for (int row = 0; row < 4; ++row)
+        for (int col = 0; col < 4; ++col) n.m[col][row] = cofactor4(&a, row, col) / det;
+    return n;
+}
+
+/* ------------------------------------------- Zig 0.9 std.math restatements */
+
+/* std.math.pow(f32, x, y), Zig 0.9 lib/std/math/pow.zig — a port of Go's
+ * math.Pow (golang.org/src/math/pow.go): integer part of y by repeated squaring
+ * on the frexp'd significand, fractional part via exp(yf*ln(x)). */
+static int is_odd_integer(float y) {
+    float ip;
+    float fp = modff(y, &ip);
+    return fp == 0 && (((int64_t)ip) & 1) == 1;
+}
+
+static float zig_pow(float x, float y) {
+    if (y == 0 || x == 1) return 1;
+    if (isnan(x) || isnan(y)) return NAN;
+    if (y == 1) return x;
+    if (x == 0) {
+        if (y < 0) {
+            if (is_odd_integer(y)) return copysignf(INFINITY, x);
+            return INFINITY;
+        } else {
+            if (is_odd_integer(y)) return x;
+            return 0;
+        }
+    }
+    if (isinf(y)) {
+        if (x == -1) return 1.0f;
+        if ((fabsf(x) < 1) == (y > 0)) return 0;
+        return INFINITY;
+    }
+    if (isinf(x)) {
+        if (x < 0) return zig_pow(1 / x, -y);
+        if (y < 0) return 0;
+        if (y > 0) return INFINITY;
+    }
+    if (y == 0.5f) return sqrtf(x);
+    if (y == -0.5f) return 1 / sqrtf(x);
+
+    float yi;
+    float yf = modff(fabsf(y), &yi);
+    if (yf != 0 && x < 0) return NAN;
+    if (yi >= 2147483648.0f) return expf(y * logf(x));
+
+    float a1 = 1.0f;
+    int32_t ae = 0;
+    if (yf != 0) {
+        if (yf > 0.5f) { yf -= 1; yi += 1; }
+        a1 = expf(yf * logf(x));
+    }
+    int xe;
+    float x1 = frexpf(x, &xe);
+    int32_t i = (int32_t)yi;
+    while (i != 0) {
+        const int overflow_shift = 8 + 1;
+        if (xe < -(1 << overflow_shift) || (1 << overflow_shift) < xe) {
+            ae += xe;
+            break;
+        }
+        if ((i & 1) == 1) { a1 *= x1; ae += xe; }
+        x1 *= x1;
+        xe <<= 1;
+        if (x1 < 0.5f) { x1 += x1; xe -= 1; }
+        i >>= 1;
+    }
+    if (y < 0) { a1 = 1 / a1; ae = -ae; }
+    return ldexpf(a1, ae);
+}
+
+/* Zig 0.9 lib/std/math/{sin,cos,tan}.zig — ports of Go's math.Sin/Cos/Tan
+ * (Cephes sin.c / tan.c); with T = f32 every constant and operation is f32. */
+static const float S0 = 1.58962301576546568060E-10f, S1 = -2.50507477628578072866E-8f,
+                   S2 = 2.75573136213857245213E-6f, S3 = -1.98412698295895385996E-4f,
+                   S4 = 8.33333333332211858878E-3f, S5 = -1.66666666666666307295E-1f;
+static const float C0 = -1.13585365213876817300E-11f, C1 = 2.08757008419747316778E-9f,
+                   C2 = -2.75573141792967388112E-7f, C3 = 2.48015872888517045348E-5f,
+                   C4 = -1.38888888888730564116E-3f, C5 = 4.16666666666665929218E-2f;
+static const float pi4a = 7.85398125648498535156e-1f, pi4b = 3.77489470793079817668E-8f,
+                   pi4c = 2.69515142907905952645E-15f,
+                   m4pi = 1.273239544735162542821171882678754627704620361328125f;
+
+static float zig_sin(float x_) {
+    float x = x_;
+    if (x == 0 || isnan(x)) return x;
+    if (isinf(x)) return NAN;
+    int sign = x < 0;
+    x = fabsf(x);
+    float y = floorf(x * m4pi);
+    int32_t j = (int32_t)y;
+    if ((j & 1) == 1) { j += 1; y += 1; }
+    j &= 7;
+    if (j > 3) { j -= 4; sign = !sign; }
+    const float z = ((x - y * pi4a) - y * pi4b) - y * pi4c;
+    const float w = z * z;
+    const float r = (j == 1 || j == 2)
+        ? 1.0f - 0.5f * w + w * w * (C5 + w * (C4 + w * (C3 + w * (C2 + w * (C1 + w * C0)))))
+        : z + z * w * (S5 + w * (S4 + w * (S3 + w * (S2 + w * (S1 + w * S0)))));
+    return sign ? -r : r;
+}
+
+static float zig_cos(float x_) {
+    float x = x_;
+    if (isnan(x) || isinf(x)) return NAN;
+    int sign = 0;
+    x = fabsf(x);
+    float y = floorf(x * m4pi);
+    int32_t j = (int32_t)y;
+    if ((j & 1) == 1) { j += 1; y += 1; }
+    j &= 7;
+    if (j > 3) { j -= 4; sign = !sign; }
+    if (j > 1) sign = !sign;
+    const float z = ((x - y * pi4a) - y * pi4b) - y * pi4c;
+    const float w = z * z;
+    const float r = (j == 1 || j == 2)
+        ? z + z * w * (S5 + w * (S4 + w * (S3 + w * (S2 + w * (S1 + w * S0)))))
+        : 1.0f - 0.5f * w + w * w * (C5 + w * (C4 + w * (C3 + w * (C2 + w * (C1 + w * C0)))));
+    return sign ? -r : r;
+}
+
+static const float Tp0 = -1.30936939181383777646E4f, Tp1 = 1.15351664838587416140E6f,
+                   Tp2 = -1.79565251976484877988E7f;
+static const float Tq1 = 1.36812963470692954678E4f, Tq2 = -1.32089234440210967447E6f,
+                   Tq3 = 2.50083801823357915839E7f, Tq4 = -5.38695755929454629881E7f;
+
+static float zig_tan(float x_) {
+    float x = x_;
+    if (x == 0 || isnan(x)) return x;
+    if (isinf(x)) return NAN;
+    int sign = x < 0;
+    x = fabsf(x);
+    float y = floorf(x * m4pi);
+    int32_t j = (int32_t)y;
+    if ((j & 1) == 1) { j += 1; y += 1; }
+    const float z = ((x - y * pi4a) - y * pi4b) - y * pi4c;
+    const float w = z * z;
+    float r = (w > 1e-14f)
+        ? z + z * (w * ((Tp0 * w + Tp1) * w + Tp2) / ((((w + Tq1) * w + Tq2) * w + Tq3) * w + Tq4))
+        : z;
+    if ((j & 2) == 2) r = -1 / r;
+    return sign ? -r : r;
+}
+
+static float m_sin(float x) { return g_libm ? zig_sin(x) : sinf(x); }
+static float m_cos(float x) { return g_libm ? zig_cos(x) : cosf(x); }
+static float m_tan(float x) { return g_libm ? zig_tan(x) : tanf(x); }
+static float m_pow(float x, float y) { return g_libm ? zig_pow(x, y) : powf(x, y); }
+
+/* matrix.zig:170-222 */
+static mat4 translation(float x, float y, float z) {
+    mat4 r = {{{1, 0, 0, x}, {0, 1, 0, y}, {0, 0, 1, z}, {0, 0, 0, 1}}};
+    return r;
+}
+static mat4 scaling(float x, float y, float z) {
+    mat4 r = {{{x, 0, 0, 0}, {0, y, 0, 0}, {0, 0, z, 0}, {0, 0, 0, 1}}};
+    return r;
+}
+static mat4 rotation_x(float r) {
+    mat4 a = {{{1, 0, 0, 0}, {0, m_cos(r), -m_sin(r), 0}, {0, m_sin(r), m_cos(r), 0}, {0, 0, 0, 1}}};
+    return a;
+}
+static mat4 rotation_y(float r) {
+    mat4 a = {{{m_cos(r), 0, m_sin(r), 0}, {0, 1, 0, 0}, {-m_sin(r), 0, m_cos(r), 0}, {0, 0, 0, 1}}};
+    return a;
+}
+static mat4 rotation_z(float r) {
+    mat4 a = {{{m_cos(r), -m_sin(r), 0, 0}, {m_sin(r), m_cos(r), 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}}};
+    return a;
+}
+static mat4 shearing(float xy, float xz, float yx, float yz, float zx, float zy) {
+    mat4 a = {{{1, xy, xz, 0}, {yx, 1, yz, 0}, {zx, zy, 1, 0}, {0, 0, 0, 1}}};
+    return a;
+}
+
+/* --------------------------------------------------------------- ray.zig */
+
+typedef struct { tuple origin, direction; } ray;
+
+static tuple position(ray r, float t) { return tadd(r.origin, tmuls(r.direction, t)); } /* ray.zig:9-11 */
+
+static ray ray_transform(ray r, mat4 m) { /* ray.zig:13-18 */
+    ray o = {mul_tuple(m, r.origin), mul_tuple(m, r.direction)};
+    return o;
+}
+
+/* ------------------------------------------------- shape.zig / intersection */
+
+enum { K_SPHERE, K_PLANE, K_CUBE, K_CYLINDER, K_CONE, K_TRIANGLE };
+
+/* shape.zig:11-18 — tagged union, by value. */
+typedef struct {
+    int kind;
+    union {
+        rt_sphere   sphere;
+        rt_plane    plane;
+        rt_cube     cube;
+        rt_cylinder cylinder;
+        rt_cone     cone;
+        rt_triangle triangle;
+    } u;
+} shape;
+
+/* intersection.zig:9-12 — the shape travels by value. */
+typedef struct { float t; shape s; } intersection;
+
+typedef struct { intersection* items; size_t len, cap; } xs_list;
+
+static void xs_append(xs_list* xs, const intersection* x) {
+    if (xs->len == xs->cap) {
+        xs->cap = xs->cap ? xs->cap * 2 : 8;
+        xs->items = (intersection*)realloc(xs->items, xs->cap * sizeof(intersection));
+    }
+    xs->items[xs->len++] = *x;
+}
+
+static void append_hit(xs_list* xs, float t, int kind, const void* self, size_t size) {
+    intersection x;
+    memset(&x, 0, sizeof x);
+    x.t = t;
+    x.s.kind = kind;
+    memcpy(&x.s.u, self, size);
+    xs_append(xs, &x);
+}
+
+/* intersection.zig:14-22 — std.sort.sort is a stable sort, lessThan = a.t < b.t.
+ * Insertion sort is stable and the lists are short. */
+static void sort_intersections(intersection* xs, size_t n) {
+    for (size_t i = 1; i < n; ++i) {
+        if (!(xs[i].t < xs[i - 1].t)) continue;
+        intersection key = xs[i];
+        size_t j = i;
+        while (j > 0 && key.t < xs[j - 1].t) {
+            xs[j] = xs[j - 1];
+            --j;
+        }
+        xs[j] = key;
+    }
+}
+
+/* intersection.zig:24-28 */
+static const intersection* hit(intersection* xs, size_t n) {
+    sort_intersections(xs, n);
+    for (size_t i = 0; i < n; ++i)
+        if (xs[i].t >= 0) return &xs[i];
+    return NULL;
+}
+
+static const rt_attrs* shape_attrs(const shape* s) {
+    switch (s->kind) {
+    case K_SPHERE: return &s->u.sphere.common_attrs;
+    case K_PLANE: return &s->u.plane.common_attrs;
+    case K_CUBE: return &s->u.cube.common_attrs;
+    case K_CYLINDER: return &s->u.cylinder.common_attrs;
+    case K_CONE: return &s->u.cone.common_attrs;
+    default: return &s->u.triangle.common_attrs;
+    }
+}
+
+/* std.meta.eql on the structs: field-wise ==, floats by value. */
+static int feq_n(const float* a, const float* b, int n) {
+    for (int i = 0; i < n; ++i)
+        if (!(a[i] == b[i])) return 0;
+    return 1;
+}
+static int pattern_eql(const rt_pattern* a, const rt_pattern* b) {
+    return feq_n(a->a, b->a, 3) && feq_n(a->b, b->b, 3) &&
+           feq_n(&a->transform.m[0][0], &b->transform.m[0][0], 16) && a->color_map == b->color_map;
+}
+static int material_eql(const rt_material* a, const rt_material* b) {
+    if (!feq_n(a->color, b->color, 3)) return 0;
+    if ((a->has_pattern != 0) != (b->has_pattern != 0)) return 0;
+    if (a->has_pattern && !pattern_eql(&a->pattern, &b->pattern)) return 0;
+    return a->ambient == b->ambient && a->diffuse == b->diffuse && a->specular == b->specular &&
+           a->shininess == b->shininess && a->reflective == b->reflective &&
+           a->refractive_index == b->refractive_index && a->transparency == b->transparency;
+}
+static int attrs_eql(const rt_attrs* a, const rt_attrs* b) {
+    return feq_n(&a->transform.m[0][0], &b->transform.m[0][0], 16) && material_eql(&a->material, &b->material);
+}
+static int shape_eql(const shape* a, const shape* b) {
+    if (a->kind != b->kind) return 0;
+    if (!attrs_eql(shape_attrs(a), shape_attrs(b))) return 0;
+    switch (a->kind) {
+    case K_CYLINDER:
+        return a->u.cylinder.minimum == b->u.cylinder.minimum && a->u.cylinder.maximum == b->u.cylinder.maximum &&
+               (a->u.cylinder.closed != 0) == (b->u.cylinder.closed != 0);
+    case K_CONE:
+        return a->u.cone.minimum == b->u.cone.minimum && a->u.cone.maximum == b->u.cone.maximum &&
+               (a->u.cone.closed != 0) == (b->u.cone.closed != 0);
+    case K_TRIANGLE:
+        return feq_n(a->u.triangle.p0, b->u.triangle.p0, 4) && feq_n(a->u.triangle.p1, b->u.triangle.p1, 4) &&
+               feq_n(a->u.triangle.p2, b->u.triangle.p2, 4) && feq_n(a->u.triangle.e0, b->u.triangle.e0, 4) &&
+               feq_n(a->u.triangle.e1, b->u.triangle.e1, 4) && feq_n(a->u.triangle.normal, b->u.triangle.normal, 4);
+    default:
+        return 1;
+    }
+}
+static int intersection_eql(const intersection* a, const intersection* b) {
+    return a->t == b->t && shape_eql(&a->s, &b->s);
+}
+
+static tuple tup_from(const float* p) { return tup4(p[0], p[1], p[2], p[3]); }
+
+/* std.math.approxEqAbs(f32, x, y, tol) */
+static int approx_eq_abs(float x, float y, float tol) {
+    if (x == y) return 1;
+    if (isnan(x) || isnan(y)) return 0;
+    return fabsf(x - y) <= tol;
+}
+
+/* ------------------------------------------------------------ sphere.zig */
+
+static void sphere_intersect(const rt_sphere* self, ray r, xs_list* xs) { /* sphere.zig:11-54 */
+    ray rp = ray_transform(r, inverse(self->common_attrs.transform));
+    tuple sphere_to_ray = tsub(rp.origin, point(0, 0, 0));
+    float a = dot(rp.direction, rp.direction);
+    float b = 2 * dot(rp.direction, sphere_to_ray);
+    float c = dot(sphere_to_ray, sphere_to_ray) - 1;
+    float discriminant = b * b - 4 * a * c;
+    if (discriminant >= 0) {
+        float t0 = (-b - sqrtf(discriminant)) / (2 * a);
+        float t1 = (-b + sqrtf(discriminant)) / (2 * a);
+        append_hit(xs, t0, K_SPHERE, self, sizeof *self);
+        append_hit(xs, t1, K_SPHERE, self, sizeof *self);
+    }
+}
+
+static tuple sphere_normal_at(const rt_sphere* s, tuple world_point) { /* sphere.zig:56-82 */
+    mat4 inv = inverse(s->common_attrs.transform);
+    tuple object_point = mul_tuple(inv, world_point);
+    tuple object_normal = tsub(object_point, point(0, 0, 0));
+    tuple world_normal = mul_tuple(transpose(inv), object_normal);
+    world_normal.v[3] = 0;
+    return normalize(world_normal);
+}
+
+/* ------------------------------------------------------------- plane.zig */
+
+static void plane_intersect(const rt_plane* self, ray r, xs_list* xs) { /* plane.zig:13-28 */
+    ray rp = ray_transform(r, inverse(self->common_attrs.transform));
+    if (fabsf(rp.direction.v[1]) < epsilon) return;
+    float t = -rp.origin.v[1] / rp.direction.v[1];
+    append_hit(xs, t, K_PLANE, self, sizeof *self);
+}
+
+static tuple plane_normal_at(const rt_plane* self, tuple world_point) { /* plane.zig:30-46 */
+    (void)world_point;
+    tuple n = mul_tuple(transpose(inverse(self->common_attrs.transform)), vector(0, 1, 0));
+    n.v[3] = 0;
+    return normalize(n);
+}
+
+/* -------------------------------------------------------------- cube.zig */
+
+typedef struct { float tmin, tmax; } tminmax;
+
+static tminmax cube_check_axis(float origin, float direction) { /* cube.zig:52-67 */
+    float tmin_numerator = -1 - origin;
+    float tmax_numerator = 1 - origin;
+    float tmin, tmax;
+    if (fabsf(direction) >= epsilon) {
+        tmin = tmin_numerator / direction;
+        tmax = tmax_numerator / direction;
+    } else {
+        tmin = tmin_numerator * INFINITY;
+        tmax = tmax_numerator * INFINITY;
+    }
+    tminmax r;
+    if (tmin > tmax) { r.tmin = tmax; r.tmax = tmin; } else { r.tmin = tmin; r.tmax = tmax; }
+    return r;
+}
+
+/* @maximum/@minimum lower to llvm.maxnum/minnum: a NaN operand is ignored,
+ * which is fmaxf/fminf. */
+static void cube_intersect(const rt_cube* self, ray r, xs_list* xs) { /* cube.zig:11-26 */
+    ray rp = ray_transform(r, inverse(self->common_attrs.transform));
+    tminmax x = cube_check_axis(rp.origin.v[0], rp.direction.v[0]);
+    tminmax y = cube_check_axis(rp.origin.v[1], rp.direction.v[1]);
+    tminmax z = cube_check_axis(rp.origin.v[2], rp.direction.v[2]);
+    float tmin = fmaxf(x.tmin, fmaxf(y.tmin, z.tmin));
+    float tmax = fminf(x.tmax, fminf(y.tmax, z.tmax));
+    if (tmin > tmax) return;
+    append_hit(xs, tmin, K_CUBE, self, sizeof *self);
+    append_hit(xs, tmax, K_CUBE, self, sizeof *self);
+}
+
+static tuple cube_normal_at(const rt_cube* self, tuple world_point) { /* cube.zig:28-44 */
+    mat4 inv = inverse(self->common_attrs.transform);
+    tuple object_point = mul_tuple(inv, world_point);
+    float x = fabsf(object_point.v[0]);
+    float y = fabsf(object_point.v[1]);
+    float z = fabsf(object_point.v[2]);
+    float maxc = fmaxf(x, fmaxf(y, z));
+    tuple object_normal;
+    if (maxc == x) object_normal = vector(object_point.v[0], 0, 0);
+    else if (maxc == y) object_normal = vector(0, object_point.v[1], 0);
+    else object_normal = vector(0, 0, object_point.v[2]);
+    /* NOTE cube.zig:43 does not reset w before normalising. */
+    return normalize(mul_tuple(transpose(inv), object_normal));
+}
+
+/* ---------------------------------------------------------- cylinder.zig */
+
+static int cyl_check_cap(ray r, float t) { /* cylinder.zig:95-101 */
+    float x = fmaf(t, r.direction.v[0], r.origin.v[0]);
+    float z = fmaf(t, r.direction.v[2], r.origin.v[2]);
+    return (x * x + z * z) <= 1;
+}
+
+static void cyl_intersect_caps(const rt_cylinder* self, ray rp, xs_list* xs) { /* cylinder.zig:53-71 */
+    if (!self->closed || approx_eq_abs(rp.direction.v[1], 0, epsilon)) return;
+    float t_lower = (self->minimum - rp.origin.v[1]) / rp.direction.v[1];
+    if (cyl_check_cap(rp, t_lower)) append_hit(xs, t_lower, K_CYLINDER, self, sizeof *self);
+    float t_upper = (self->maximum - rp.origin.v[1]) / rp.direction.v[1];
+    if (cyl_check_cap(rp, t_upper)) append_hit(xs, t_upper, K_CYLINDER, self, sizeof *self);
+}
+
+static void cylinder_intersect(const rt_cylinder* self, ray r, xs_list* xs) { /* cylinder.zig:14-51 */
+    ray rp = ray_transform(r, inverse(self->common_attrs.transform));
+    float a = rp.direction.v[0] * rp.direction.v[0] + rp.direction.v[2] * rp.direction.v[2];
+    if (approx_eq_abs(a, 0, epsilon)) {
+        cyl_intersect_caps(self, rp, xs);
+        return;
+    }
+    float b = 2 * rp.origin.v[0] * rp.direction.v[0] + 2 * rp.origin.v[2] * rp.direction.v[2];
+    float c = rp.origin.v[0] * rp.origin.v[0] + rp.origin.v[2] * rp.origin.v[2] - 1;
+    float discriminant = b * b - 4 * a * c;
+    if (discriminant < 0) {
+        cyl_intersect_caps(self, rp, xs);
+        return;
+    }
+    float t0 = (-b - sqrtf(discriminant)) / (2 * a);
+    float t1 = (-b + sqrtf(discriminant)) / (2 * a);
+    if (t0 > t1) { float tmp = t0; t0 = t1; t1 = tmp; }
+
+    float y0 = fmaf(t0, rp.direction.v[1], rp.origin.v[1]);
+    if (self->minimum < y0 && y0 < self->maximum) append_hit(xs, t0, K_CYLINDER, self, sizeof *self);
+    float y1 = fmaf(t1, rp.direction.v[1], rp.origin.v[1]);
+    if (self->minimum < y1 && y1 < self->maximum) append_hit(xs, t1, K_CYLINDER, self, sizeof *self);
+
+    cyl_intersect_caps(self, rp, xs);
+}
+
+static tuple cylinder_normal_at(const rt_cylinder* self, tuple world_point) { /* cylinder.zig:73-92 */
+    mat4 inv = inverse(self->common_attrs.transform);
+    tuple object_normal;
+    tuple object_point = mul_tuple(inv, world_point);
+    float distance = object_point.v[0] * object_point.v[0] + object_point.v[2] * object_point.v[2];
+    if (distance < 1 && object_point.v[1] >= self->maximum - epsilon) {
+        object_normal = vector(0, 1, 0);
+    } else if (distance < 1 && object_point.v[1] <= self->minimum + epsilon) {
+        object_normal = vector(0, -1, 0);
+    } else {
+        object_normal = vector(object_point.v[0], 0, object_point.v[2]);
+    }
+    tuple world_normal = mul_tuple(transpose(inv), object_normal);
+    world_normal.v[3] = 0;
+    return normalize(world_normal);
+}
+
+/* -------------------------------------------------------------- cone.zig */
+
+static int cone_check_cap(ray r, float t, float y) { /* cone.zig:108-114 */
+    float x = fmaf(t, r.direction.v[0], r.origin.v[0]);
+    float z = fmaf(t, r.direction.v[2], r.origin.v[2]);
+    return (x * x + z * z) <= fabsf(y * y);
+}
+
+static void cone_intersect_caps(const rt_cone* self, ray rp, xs_list* xs) { /* cone.zig:66-82 */
+    if (!self->closed || approx_eq_abs(rp.direction.v[1], 0, epsilon)) return;
+    float t_lower = (self->minimum - rp.origin.v[1]) / rp.direction.v[1];
+    if (cone_check_cap(rp, t_lower, self->minimum)) append_hit(xs, t_lower, K_CONE, self, sizeof *self);
+    float t_upper = (self->maximum - rp.origin.v[1]) / rp.direction.v[1];
+    if (cone_check_cap(rp, t_upper, self->maximum)) append_hit(xs, t_upper, K_CONE, self, sizeof *self);
+}
+
+static void cone_intersect(const rt_cone* self, ray r, xs_list* xs) { /* cone.zig:14-64 */
+    ray rp = ray_transform(r, inverse(self->common_attrs.transform));
+    float a = rp.direction.v[0] * rp.direction.v[0] - rp.direction.v[1] * rp.direction.v[1] +
+              rp.direction.v[2] * rp.direction.v[2];
+    float b = 2 * rp.origin.v[0] * rp.direction.v[0] - 2 * rp.origin.v[1] * rp.direction.v[1] +
+              2 * rp.origin.v[2] * rp.direction.v[2];
+    float c = rp.origin.v[0] * rp.origin.v[0] - rp.origin.v[1] * rp.origin.v[1] +
+              rp.origin.v[2] * rp.origin.v[2];
+    if (approx_eq_abs(a, 0, epsilon)) {
+        if (approx_eq_abs(b, 0, epsilon)) {
+            cone_intersect_caps(self, rp, xs);
+            return;
+        } else {
+            float t = -c / (2 * b);
+            append_hit(xs, t, K_CONE, self, sizeof *self);
+            cone_intersect_caps(self, rp, xs);
+            return;
+        }
+    }
+    float discriminant = b * b - 4 * a * c;
+    if (discriminant < 0) {
+        cone_intersect_caps(self, rp, xs);
+        return;
+    }
+    float t0 = (-b - sqrtf(discriminant)) / (2 * a);
+    float t1 = (-b + sqrtf(discriminant)) / (2 * a);
+    if (t0 > t1) { float tmp = t0; t0 = t1; t1 = tmp; }
+
+    float y0 = fmaf(t0, rp.direction.v[1], rp.origin.v[1]);
+    if (self->minimum < y0 && y0 < self->maximum) append_hit(xs, t0, K_CONE, self, sizeof *self);
+    float y1 = fmaf(t1, rp.direction.v[1], rp.origin.v[1]);
+    if (self->minimum < y1 && y1 < self->maximum) append_hit(xs, t1, K_CONE, self, sizeof *self);
+
+    cone_intersect_caps(self, rp, xs);
+}
+
+static tuple cone_normal_at(const rt_cone* self, tuple world_point) { /* cone.zig:84-105 */
+    mat4 inv = inverse(self->common_attrs.transform);
+    tuple object_normal;
+    tuple object_point = mul_tuple(inv, world_point);
+    float distance = object_point.v[0] * object_point.v[0] + object_point.v[2] * object_point.v[2];
+    if (distance < self->maximum * self->maximum && object_point.v[1] >= self->maximum - epsilon) {
+        object_normal = vector(0, 1, 0);
+    } else if (distance < self->minimum * self->minimum && object_point.v[1] <= self->minimum + epsilon) {
+        object_normal = vector(0, -1, 0);
+    } else {
+        float y = (object_point.v[1] > 0) ? -sqrtf(distance) : sqrtf(distance);
+        object_normal = vector(object_point.v[0], y, object_point.v[2]);
+    }
+    tuple world_normal = mul_tuple(transpose(inv), object_normal);
+    world_normal.v[3] = 0;
+    return normalize(world_normal);
+}
+
+/* ---------------------------------------------------------- triangle.zig */
+
+static void triangle_intersect(const rt_triangle* self, ray r, xs_list* xs) { /* triangle.zig:32-50 */
+    ray rp = ray_transform(r, inverse(self->common_attrs.transform));
+    tuple e0 = tup_from(self->e0), e1 = tup_from(self->e1), p0 = tup_from(self->p0);
+    tuple dir_cross_e1 = cross(rp.direction, e1);
+    float det = dot(e0, dir_cross_e1);
+    if (fabsf(det) < epsilon) return;
+    float f = 1.0f / det;
+    tuple p0_to_origin = tsub(rp.origin, p0);
+    float u = f * dot(p0_to_origin, dir_cross_e1);
+    if (u < 0 || u > 1) return;
+    tuple origin_cross_e0 = cross(p0_to_origin, e0);
+    float v = f * dot(rp.direction, origin_cross_e0);
+    if (v < 0 || (u + v) > 1) return;
+    float t = f * dot(e1, origin_cross_e0);
+    append_hit(xs, t, K_TRIANGLE, self, sizeof *self);
+}
+
+static tuple triangle_normal_at(const rt_triangle* self, tuple world_point) { /* triangle.zig:52-61 */
+    (void)world_point;
+    mat4 inv = inverse(self->common_attrs.transform);
+    tuple world_normal = mul_tuple(transpose(inv), tup_from(self->normal));
+    world_normal.v[3] = 0;
+    return normalize(world_normal);
+}
+
+/* ------------------------------------------------------------ bounds.zig */
+
+static tminmax bounds_check_axis(float min, float max, float origin, float direction) { /* bounds.zig:160-175 */
+    float tmin_numerator = min - origin;
+    float tmax_numerator = max - origin;
+    float tmin, tmax;
+    if (fabsf(direction) >= epsilon) {
+        tmin = tmin_numerator / direction;
+        tmax = tmax_numerator / direction;
+    } else {
+        tmin = tmin_numerator * INFINITY;
+        tmax = tmax_numerator * INFINITY;
+    }
+    tminmax r;
+    if (tmin > tmax) { r.tmin = tmax; r.tmax = tmin; } else { r.tmin = tmin; r.tmax = tmax; }
+    return r;
+}
+
+static int bounds_intersect(const rt_bounds* b, ray r) { /* bounds.zig:149-158 */
+    tminmax x = bounds_check_axis(b->minimum[0], b->maximum[0], r.origin.v[0], r.direction.v[0]);
+    tminmax y = bounds_check_axis(b->minimum[1], b->maximum[1], r.origin.v[1], r.direction.v[1]);
+    tminmax z = bounds_check_axis(b->minimum[2], b->maximum[2], r.origin.v[2], r.direction.v[2]);
+    float tmin = fmaxf(x.tmin, fmaxf(y.tmin, z.tmin));
+    float tmax = fminf(x.tmax, fminf(y.tmax, z.tmax));
+    return tmin <= tmax;
+}
+
+static void bset(rt_bounds* b, tuple mn, tuple mx) {
+    memcpy(b->minimum, mn.v, sizeof b->minimum);
+    memcpy(b->maximum, mx.v, sizeof b->maximum);
+}
+
+static void merge_point(rt_bounds* b, tuple p) { /* bounds.zig:114-117, lane-wise incl. w */
+    for (int i = 0; i < 4; ++i) {
+        b->minimum[i] = fminf(b->minimum[i], p.v[i]);
+        b->maximum[i] = fmaxf(b->maximum[i], p.v[i]);
+    }
+}
+
+static void merge_bounds(rt_bounds* a, const rt_bounds* b) { /* bounds.zig:109-112 */
+    for (int i = 0; i < 4; ++i) {
+        a->minimum[i] = fminf(a->minimum[i], b->minimum[i]);
+        a->maximum[i] = fmaxf(a->maximum[i], b->maximum[i]);
+    }
+}
+
+/* bounds.zig:119-133 — seeded with the untransformed box; six of the eight
+ * corners only. */
+static rt_bounds transform_bounds(const rt_bounds* b, mat4 transform) {
+    rt_bounds bp = *b;
+    const float* mn = b->minimum;
+    const float* mx = b->maximum;
+    tuple points[6] = {
+        tup4(mn[0], mn[1], mx[2], 1), tup4(mn[0], mx[1], mn[2], 1), tup4(mn[0], mx[1], mx[2], 1),
+        tup4(mx[0], mn[1], mn[2], 1), tup4(mx[0], mn[1], mx[2], 1), tup4(mx[0], mx[1], mn[2], 1),
+    };
+    for (int i = 0; i < 6; ++i) merge_point(&bp, mul_tuple(transform, points[i]));
+    return bp;
+}
+
+static rt_bounds bound_group(const rt_group* group);
+
+static rt_bounds shape_bounds_unit(void) { /* bounds.zig:39-45,55-61 */
+    rt_bounds b;
+    bset(&b, point(-1, -1, -1), point(1, 1, 1));
+    return b;
+}
+
+static rt_bounds bound_group(const rt_group* g) { /* bounds.zig:85-107 */
+    rt_bounds gb;
+    bset(&gb, point(INFINITY, INFINITY, INFINITY), point(-INFINITY, -INFINITY, -INFINITY));
+    rt_bounds sb, tb;
+    for (uint32_t i = 0; i < g->n_spheres; ++i) {
+        sb = shape_bounds_unit();
+        tb = transform_bounds(&sb, mul_matrix(g->transform, g->spheres[i].common_attrs.transform));
+        merge_bounds(&gb, &tb);
+    }
+    for (uint32_t i = 0; i < g->n_planes; ++i) { /* bounds.zig:47-53 */
+        bset(&sb, point(-INFINITY, 0, -INFINITY), point(INFINITY, 0, INFINITY));
+        tb = transform_bounds(&sb, mul_matrix(g->transform, g->planes[i].common_attrs.transform));
+        merge_bounds(&gb, &tb);
+    }
+    for (uint32_t i = 0; i < g->n_cubes; ++i) {
+        sb = shape_bounds_unit();
+        tb = transform_bounds(&sb, mul_matrix(g->transform, g->cubes[i].common_attrs.transform));
+        merge_bounds(&gb, &tb);
+    }
+    for (uint32_t i = 0; i < g->n_cylinders; ++i) { /* bounds.zig:63-68 */
+        const rt_cylinder* c = &g->cylinders[i];
+        bset(&sb, point(-1, c->minimum, -1), point(1, c->maximum, 1));
+        tb = transform_bounds(&sb, mul_matrix(g->transform, c->common_attrs.transform));
+        merge_bounds(&gb, &tb);
+    }
+    for (uint32_t i = 0; i < g->n_cones; ++i) { /* bounds.zig:70-76 */
+        const rt_cone* c = &g->cones[i];
+        float xz = fmaxf(fabsf(c->minimum), fabsf(c->maximum));
+        bset(&sb, point(-xz, c->minimum, -xz), point(xz, c->maximum, xz));
+        tb = transform_bounds(&sb, mul_matrix(g->transform, c->common_attrs.transform));
+        merge_bounds(&gb, &tb);
+    }
+    for (uint32_t i = 0; i < g->n_triangles; ++i) { /* bounds.zig:78-83 */
+        const rt_triangle* t = &g->triangles[i];
+        for (int k = 0; k < 4; ++k) {
+            sb.minimum[k] = fminf(t->p0[k], fminf(t->p1[k], t->p2[k]));
+            sb.maximum[k] = fmaxf(t->p0[k], fmaxf(t->p1[k], t->p2[k]));
+        }
+        tb = transform_bounds(&sb, mul_matrix(g->transform, t->common_attrs.transform));
+        merge_bounds(&gb, &tb);
+    }
+    for (uint32_t i = 0; i < g->n_subgroups; ++i) { /* bounds.zig:140-142 */
+        sb = bound_group(&g->subgroups[i]);
+        tb = transform_bounds(&sb, g->transform);
+        merge_bounds(&gb, &tb);
+    }
+    return gb;
+}
+
+/* ------------------------------------------------------------- group.zig */
+
+/* group.zig:55-87.  The reference temporarily overwrites subgroup.transform
+ * with mul(g.transform, original) around the recursive call (:72-83); passing
+ * the composed transform down is the same arithmetic without the mutation. */
+static void group_intersect(const rt_group* g, mat4 g_transform, ray r, xs_list* xs) {
+    if (!g->has_bounding_box || bounds_intersect(&g->bounding_box, r)) {
+        for (uint32_t i = 0; i < g->n_spheres; ++i) {
+            rt_sphere s = g->spheres[i]; /* transformShape, group.zig:101-106 */
+            s.common_attrs.transform = mul_matrix(g_transform, g->spheres[i].common_attrs.transform);
+            sphere_intersect(&s, r, xs);
+        }
+        for (uint32_t i = 0; i < g->n_planes; ++i) {
+            rt_plane s = g->planes[i];
+            s.common_attrs.transform = mul_matrix(g_transform, g->planes[i].common_attrs.transform);
+            plane_intersect(&s, r, xs);
+        }
+        for (uint32_t i = 0; i < g->n_cubes; ++i) {
+            rt_cube s = g->cubes[i];
+            s.common_attrs.transform = mul_matrix(g_transform, g->cubes[i].common_attrs.transform);
+            cube_intersect(&s, r, xs);
+        }
+        for (uint32_t i = 0; i < g->n_cylinders; ++i) {
+            rt_cylinder s = g->cylinders[i];
+            s.common_attrs.transform = mul_matrix(g_transform, g->cylinders[i].common_attrs.transform);
+            cylinder_intersect(&s, r, xs);
+        }
+        for (uint32_t i = 0; i < g->n_cones; ++i) {
+            rt_cone s = g->cones[i];
+            s.common_attrs.transform = mul_matrix(g_transform, g->cones[i].common_attrs.transform);
+            cone_intersect(&s, r, xs);
+        }
+        for (uint32_t i = 0; i < g->n_triangles; ++i) {
+            rt_triangle s = g->triangles[i];
+            s.common_attrs.transform = mul_matrix(g_transform, g->triangles[i].common_attrs.transform);
+            triangle_intersect(&s, r, xs);
+        }
+        for (uint32_t i = 0; i < g->n_subgroups; ++i) {
+            const rt_group* sub = &g->subgroups[i];
+            group_intersect(sub, mul_matrix(g_transform, sub->transform), r, xs);
+        }
+        sort_intersections(xs->items, xs->len);
+    }
+}
+
+/* ----------------------------------------------------------- pattern.zig */
+
+static color col3(const float* p) { color c = {{p[0], p[1], p[2]}}; return c; }
+
+/* @mod(x, 2) == 0 with floored modulo: true exactly when fmodf(x, 2) is +-0. */
+static int mod2_is_zero(float x) { return fmodf(x, 2.0f) == 0.0f; }
+
+static color pattern_at(const rt_pattern* p, tuple pt) {
+    color a = col3(p->a), b = col3(p->b);
+    switch (p->color_map) {
+    case RT_PATTERN_STRIPE: /* pattern.zig:33-35 */
+        return mod2_is_zero(floorf(pt.v[0])) ? a : b;
+    case RT_PATTERN_GRADIENT: { /* pattern.zig:37-41 */
+        float fraction = pt.v[0] - floorf(pt.v[0]);
+        color r;
+        for (int i = 0; i < 3; ++i) {
+            float distance = b.c[i] - a.c[i];
+            r.c[i] = a.c[i] + distance * fraction;
+        }
+        return r;
+    }
+    case RT_PATTERN_RING: { /* pattern.zig:43-46 */
+        float c = floorf(sqrtf(pt.v[0] * pt.v[0] + pt.v[2] * pt.v[2]));
+        return mod2_is_zero(c) ? a : b;
+    }
+    default: { /* checker, pattern.zig:48-51 */
+        float c = floorf(pt.v[0]) + floorf(pt.v[1]) + floorf(pt.v[2]);
+        return mod2_is_zero(c) ? a : b;
+    }
+    }
+}
+
+static color pattern_at_shape(const rt_pattern* p, const rt_attrs* attrs, tuple world_point) { /* pattern.zig:23-31 */
+    tuple object_point = mul_tuple(inverse(attrs->transform), world_point);
+    tuple pattern_point = mul_tuple(inverse(p->transform), object_point);
+    return pattern_at(p, pattern_point);
+}
+
+/* ---------------------------------------------------------- material.zig */
+
+static color lighting(const rt_attrs* attrs, tuple light_position, color light_intensity,
+                      tuple pt, tuple eye, tuple normal, int in_shadow) { /* material.zig:40-102 */
+    const rt_material* material = &attrs->material;
+    color c;
+    if (material->has_pattern) c = pattern_at_shape(&material->pattern, attrs, pt);
+    else c = col3(material->color);
+
+    color effective_color, ambient, diffuse, specular, out;
+    for (int i = 0; i < 3; ++i) effective_color.c[i] = c.c[i] * light_intensity.c[i];
+    tuple light_direction = normalize(tsub(light_position, pt));
+    for (int i = 0; i < 3; ++i) ambient.c[i] = effective_color.c[i] * material->ambient;
+    if (in_shadow) return ambient;
+
+    float cos_light_normal = dot(light_direction, normal);
+    if (cos_light_normal < 0) {
+        for (int i = 0; i < 3; ++i) diffuse.c[i] = specular.c[i] = 0;
+    } else {
+        for (int i = 0; i < 3; ++i) diffuse.c[i] = effective_color.c[i] * material->diffuse * cos_light_normal;
+        tuple refl = reflect(tneg(light_direction), normal);
+        float cos_reflect_eye = dot(refl, eye);
+        if (cos_reflect_eye <= 0) {
+            for (int i = 0; i < 3; ++i) specular.c[i] = 0;
+        } else {
+            float factor = m_pow(cos_reflect_eye, material->shininess);
+            for (int i = 0; i < 3; ++i) specular.c[i] = light_intensity.c[i] * material->specular * factor;
+        }
+    }
+    for (int i = 0; i < 3; ++i) out.c[i] = ambient.c[i] + diffuse.c[i] + specular.c[i];
+    return out;
+}
+
+/* ------------------------------------------------------ intersection.zig */
+
+typedef struct { /* intersection.zig:30-41 */
+    float t;
+    rt_attrs shape_attrs;
+    tuple point, eye, normal;
+    float n1, n2;
+    tuple reflect;
+} computation;
+
+static computation prepare_computations(const intersection* i, ray r) { /* intersection.zig:43-90 */
+    computation comps;
+    comps.t = i->t;
+    comps.point = position(r, i->t);
+    comps.eye = tneg(r.direction);
+    comps.shape_attrs = *shape_attrs(&i->s);
+    switch (i->s.kind) {
+    case K_SPHERE: comps.normal = sphere_normal_at(&i->s.u.sphere, comps.point); break;
+    case K_PLANE: comps.normal = plane_normal_at(&i->s.u.plane, comps.point); break;
+    case K_CUBE: comps.normal = cube_normal_at(&i->s.u.cube, comps.point); break;
+    case K_CYLINDER: comps.normal = cylinder_normal_at(&i->s.u.cylinder, comps.point); break;
+    case K_CONE: comps.normal = cone_normal_at(&i->s.u.cone, comps.point); break;
+    default: comps.normal = triangle_normal_at(&i->s.u.triangle, comps.point); break;
+    }
+    if (dot(comps.normal, comps.eye) < 0) comps.normal = tneg(comps.normal);
+    comps.reflect = reflect(r.direction, comps.normal);
+    comps.n1 = NAN; /* undefined in the reference until the refraction walk sets them */
+    comps.n2 = NAN;
+    return comps;
+}
+
+/* intersection.zig:92-159 — the container walk, literal: std.meta.eql compares
+ * whole Intersections (t included) unless the "book" switch is on. */
+static int container_match(const intersection* a, const intersection* b) {
+    return g_containers_book ? shape_eql(&a->s, &b->s) : intersection_eql(a, b);
+}
+
+static computation prepare_computations_for_refraction(const intersection* i, ray r,
+                                                        const intersection* xs, size_t n) {
+    computation comps = prepare_computations(i, r);
+    const intersection** containers = (const intersection**)malloc((n + 1) * sizeof *containers);
+    size_t len = 0;
+    for (size_t k = 0; k < n; ++k) {
+        const intersection* x = &xs[k];
+        int is_hit = intersection_eql(x, i);
+        if (is_hit) {
+            if (len == 0) comps.n1 = 1.0f;
+            else comps.n1 = shape_attrs(&containers[len - 1]->s)->material.refractive_index;
+        }
+        size_t found = len;
+        for (size_t c = 0; c < len; ++c)
+            if (container_match(containers[c], x)) { found = c; break; }
+        if (found < len) {
+            memmove(&containers[found], &containers[found + 1], (len - found - 1) * sizeof *containers);
+            --len;
+        } else {
+            containers[len++] = x;
+        }
+        if (is_hit) {
+            if (len == 0) comps.n2 = 1.0f;
+            else comps.n2 = shape_attrs(&containers[len - 1]->s)->material.refractive_index;
+            break;
+        }
+    }
+    free(containers);
+    return comps;
+}
+
+static float schlick(const computation* comps) { /* intersection.zig:161-180 */
+    float r0 = (comps->n1 - comps->n2) / (comps->n1 + comps->n2);
+    r0 *= r0;
+    float cosv = dot(comps->eye, comps->normal);
+    if (comps->n1 > comps->n2) {
+        float n = comps->n1 / comps->n2;
+        float sin2_t = n * n * (1.0f - cosv * cosv);
+        if (sin2_t > 1.0f) return 1.0f;
+        cosv = sqrtf(1.0f - sin2_t);
+    }
+    return r0 + (1 - r0) * m_pow(1 - cosv, 5);
+}
+
+/* ------------------------------------------------------------- world.zig */
+
+#define RAY_DEPTH_LIMIT 5 /* world.zig:20 */
+
+typedef struct {
+    const rt_world* world;
+    rt_ray_counts counts;
+    int depth_limit;
+} ctx;
+
+static void world_intersect(const rt_world* w, ray r, xs_list* xs) { /* world.zig:38-47 */
+    for (uint32_t i = 0; i < w->n_spheres; ++i) sphere_intersect(&w->spheres[i], r, xs);
+    for (uint32_t i = 0; i < w->n_planes; ++i) plane_intersect(&w->planes[i], r, xs);
+    for (uint32_t i = 0; i < w->n_cubes; ++i) cube_intersect(&w->cubes[i], r, xs);
+    for (uint32_t i = 0; i < w->n_cylinders; ++i) cylinder_intersect(&w->cylinders[i], r, xs);
+    for (uint32_t i = 0; i < w->n_cones; ++i) cone_intersect(&w->cones[i], r, xs);
+    for (uint32_t i = 0; i < w->n_triangles; ++i) triangle_intersect(&w->triangles[i], r, xs);
+    for (uint32_t i = 0; i < w->n_groups; ++i) group_intersect(&w->groups[i], w->groups[i].transform, r, xs);
+    sort_intersections(xs->items, xs->len);
+}
+
+static color color_at_internal(ctx* c, ray r, unsigned remaining);
+
+static int is_shadowed(ctx* c, tuple p) { /* world.zig:97-120 */
+    c->counts.shadow++;
+    tuple v = tsub(tup_from(c->world->light_position), p);
+    float distance = magnitude(v);
+    tuple direction = normalize(v);
+    ray shadow_ray = {p, direction};
+    xs_list xs = {0, 0, 0};
+    world_intersect(c->world, shadow_ray, &xs);
+    int shadowed = 0;
+    const intersection* h = hit(xs.items, xs.len);
+    if (h) shadowed = h->t < distance;
+    free(xs.items);
+    return shadowed;
+}
+
+/* world.zig:55,137,180: `tup.epsilon * 100.0`, an f32 product.  The factor is a
+ * switch only so the golden tests can show that the shipped images were
+ * rendered by an older revision that offset by a smaller epsilon (see
+ * tests/test_oracle_golden.py); v1 is 100 and that is the default. */
+static float over_eps_factor = 100.0f;
+EXPORT void oracle_set_over_eps_factor(float f) { over_eps_factor = f; }
+/* Golden-provenance switch, default off (= v1): evaluate Phong at comps.point
+ * instead of over_point.  v1 lights at over_point (world.zig:57-63); the shipped
+ * skewed_triangle.ppm / cone.ppm turn out to have been rendered by an older
+ * revision that lit at comps.point — with this switch on the oracle reproduces
+ * them (tests/test_oracle_golden.py), which pins everything else on the path. */
+static int legacy_light_at_point = 0;
+EXPORT void oracle_set_legacy_light_at_point(int on) { legacy_light_at_point = on; }
+
+static color reflected_color_internal(ctx* c, const computation* comps, unsigned remaining) { /* world.zig:126-143 */
+    color black = {{0, 0, 0}};
+    if (remaining == 0) return black;
+    if (comps->shape_attrs.material.reflective == 0) return black;
+    ray reflect_ray = {tadd(comps->point, tmuls(comps->normal, epsilon * over_eps_factor)), comps->reflect};
+    color col = color_at_internal(c, reflect_ray, remaining - 1);
+    for (int i = 0; i < 3; ++i) col.c[i] = col.c[i] * comps->shape_attrs.material.reflective;
+    return col;
+}
+
+static color refracted_color_internal(ctx* c, const computation* comps, unsigned remaining) { /* world.zig:149-186 */
+    color black = {{0, 0, 0}};
+    if (remaining == 0) return black;
+    if (comps->shape_attrs.material.transparency == 0) return black;
+    float n_ratio = comps->n1 / comps->n2;
+    float cos_i = dot(comps->eye, comps->normal);
+    float sin2_t = (n_ratio * n_ratio) * (1 - cos_i * cos_i);
+    if (sin2_t > 1) return black;
+    float cos_t = sqrtf(1.0f - sin2_t);
+    ray refract_ray = {
+        tsub(comps->point, tmuls(comps->normal, epsilon * over_eps_factor)),
+        tsub(tmuls(comps->normal, n_ratio * cos_i - cos_t), tmuls(comps->eye, n_ratio)),
+    };
+    color col = color_at_internal(c, refract_ray, remaining - 1);
+    for (int i = 0; i < 3; ++i) col.c[i] = col.c[i] * comps->shape_attrs.material.transparency;
+    return col;
+}
+
+static color shade_hit_internal(ctx* c, const computation* comps, unsigned remaining) { /* world.zig:54-79 */
+    tuple over_point = tadd(comps->point, tmuls(comps->normal, epsilon * over_eps_factor));
+    int shadowed = is_shadowed(c, over_point);
+    color surface = lighting(&comps->shape_attrs, tup_from(c->world->light_position),
+                             col3(c->world->light_intensity), legacy_light_at_point ? comps->point : over_point,
+                             comps->eye, comps->normal, shadowed);
+    color reflected = reflected_color_internal(c, comps, remaining);
+    color refracted = refracted_color_internal(c, comps, remaining);
+    const rt_material* material = &comps->shape_attrs.material;
+    color out;
+    if (material->reflective > 0 && material->transparency > 0) {
+        float reflectance = schlick(comps);
+        for (int i = 0; i < 3; ++i)
+            out.c[i] = surface.c[i] + reflected.c[i] * reflectance + refracted.c[i] * (1.0f - reflectance);
+        return out;
+    }
+    for (int i = 0; i < 3; ++i) out.c[i] = surface.c[i] + reflected.c[i] + refracted.c[i];
+    return out;
+}
+
+static color color_at_internal(ctx* c, ray r, unsigned remaining) { /* world.zig:85-95 */
+    if (remaining == (unsigned)c->depth_limit) c->counts.primary++;
+    else c->counts.secondary++;
+    xs_list xs = {0, 0, 0};
+    world_intersect(c->world, r, &xs);
+    color out = {{0, 0, 0}};
+    const intersection* hp = hit(xs.items, xs.len);
+    if (hp) {
+        intersection h = *hp; /* the reference copies the hit out of the optional */
+        computation comps = prepare_computations_for_refraction(&h, r, xs.items, xs.len);
+        out = shade_hit_internal(c, &comps, remaining);
+    }
+    free(xs.items);
+    return out;
+}
+
+/* ------------------------------------------------------------ camera.zig */
+
+static mat4 transform_camera_perspective(tuple from, tuple to, tuple up) { /* camera.zig:53-67 */
+    tuple forward = normalize(tsub(to, from));
+    tuple left = cross(forward, normalize(up));
+    tuple true_up = cross(left, forward);
+    mat4 orientation = {{
+        {left.v[0], left.v[1], left.v[2], 0},
+        {true_up.v[0], true_up.v[1], true_up.v[2], 0},
+        {-forward.v[0], -forward.v[1], -forward.v[2], 0},
+        {0, 0, 0, 1},
+    }};
+    return mul_matrix(orientation, translation(-from.v[0], -from.v[1], -from.v[2]));
+}
+
+EXPORT void oracle_camera(uint32_t horizontal_size, uint32_t vertical_size, float field_of_view,
+                          const float from[4], const float to[4], const float up[4], rt_camera* out) { /* camera.zig:25-51 */
+    float h = (float)horizontal_size;
+    float v = (float)vertical_size;
+    rt_camera c;
+    c.horizontal_size = horizontal_size;
+    c.vertical_size = vertical_size;
+    c.field_of_view = field_of_view;
+    c.transform = transform_camera_perspective(tup_from(from), tup_from(to), tup_from(up));
+    float half_view = m_tan(c.field_of_view / 2.0f);
+    float aspect_ratio = h / v;
+    if (aspect_ratio >= 1) {
+        c.half_width = half_view;
+        c.half_height = half_view / aspect_ratio;
+    } else {
+        c.half_width = half_view * aspect_ratio;
+        c.half_height = half_view;
+    }
+    c.pixel_size = (c.half_width * 2) / h;
+    *out = c;
+}
+
+static ray ray_for_pixel(const rt_camera* c, uint32_t px, uint32_t py) { /* camera.zig:70-82 */
+    float x_offset = ((float)px + 0.5f) * c->pixel_size;
+    float y_offset = ((float)py + 0.5f) * c->pixel_size;
+    float world_x = c->half_width - x_offset;
+    float world_y = c->half_height - y_offset;
+    tuple pixel = mul_tuple(inverse(c->transform), point(world_x, world_y, -1));
+    tuple origin = mul_tuple(inverse(c->transform), point(0, 0, 0));
+    tuple direction = normalize(tsub(pixel, origin));
+    ray r = {origin, direction};
+    return r;
+}
+
+typedef struct {
+    const rt_camera* camera;
+    const rt_world* world;
+    float* canvas;
+    uint32_t start_row, final_row, row_step;
+    int depth_limit;
+    rt_ray_counts counts;
+} thread_ctx;
+
+static void* render_internal(void* arg) { /* camera.zig:107-119 */
+    thread_ctx* t = (thread_ctx*)arg;
+    ctx c;
+    memset(&c, 0, sizeof c);
+    c.world = t->world;
+    c.depth_limit = t->depth_limit;
+    const uint32_t w = t->camera->horizontal_size;
+    for (uint32_t y = t->start_row; y < t->final_row; y += t->row_step) {
+        for (uint32_t x = 0; x < w; ++x) {
+            ray r = ray_for_pixel(t->camera, x, y);
+            color col = color_at_internal(&c, r, (unsigned)c.depth_limit);
+            float* px = t->canvas + 3 * ((size_t)y * w + x); /* canvas.zig:34-36,52-54 */
+            px[0] = col.c[0];
+            px[1] = col.c[1];
+            px[2] = col.c[2];
+        }
+    }
+    t->counts = c.counts;
+    return NULL;
+}
+
+/*
+ * camera.zig:84-105 — render().  The canvas (W*H*3 f32, row-major, zero-filled,
+ * canvas.zig:15-28) is caller-owned.  rows_quirk != 0 keeps the reference's
+ * `rows_per_thread = vsize / 8` (rows beyond 8*floor(H/8) stay black);
+ * rows_quirk == 0 gives the remainder rows to the last band.  row_step > 1
+ * renders only every row_step-th row of each band (bench sampling; other rows
+ * stay black).  Threads are the reference's 8 static row bands.
+ */
+EXPORT int oracle_render(const rt_camera* cam, const rt_world* world, float* canvas, int rows_quirk,
+                         uint32_t row_step, rt_ray_counts* counts_out) {
+    enum { number_of_threads = 8 };
+    const uint32_t h = cam->vertical_size, w = cam->horizontal_size;
+    memset(canvas, 0, (size_t)w * h * 3 * sizeof(float));
+    const uint32_t rows_per_thread = h / number_of_threads;
+    thread_ctx tc[number_of_threads];
+    pthread_t threads[number_of_threads];
+    if (row_step == 0) row_step = 1;
+    for (uint32_t i = 0; i < number_of_threads; ++i) {
+        memset(&tc[i], 0, sizeof tc[i]);
+        tc[i].camera = cam;
+        tc[i].world = world;
+        tc[i].canvas = canvas;
+        tc[i].start_row = i * rows_per_thread;
+        tc[i].final_row = tc[i].start_row + rows_per_thread;
+        if (!rows_quirk && i == number_of_threads - 1) tc[i].final_row = h;
+        tc[i].row_step = row_step;
+        tc[i].depth_limit = RAY_DEPTH_LIMIT;
+        if (pthread_create(&threads[i], NULL, render_internal, &tc[i]) != 0) return -1;
+    }
+    rt_ray_counts total = {0, 0, 0};
+    for (uint32_t i = 0; i < number_of_threads; ++i) {
+        pthread_join(threads[i], NULL);
+        total.primary += tc[i].counts.primary;
+        total.shadow += tc[i].counts.shadow;
+        total.secondary += tc[i].counts.secondary;
+    }
+    if (counts_out) *counts_out = total;
+    return 0;
+}
+
+/* world.zig:81-83 — colorAt for one ray. */
+EXPORT void oracle_color_at(const rt_world* world, const rt_ray* r, float rgb[3]) {
+    ctx c;
+    memset(&c, 0, sizeof c);
+    c.world = world;
+    c.depth_limit = RAY_DEPTH_LIMIT;
+    ray rr = {tup_from(r->origin), tup_from(r->direction)};
+    color col = color_at_internal(&c, rr, RAY_DEPTH_LIMIT);
+    rgb[0] = col.c[0];
+    rgb[1] = col.c[1];
+    rgb[2] = col.c[2];
+}
+
+EXPORT void oracle_ray_for_pixel(const rt_camera* c, uint32_t px, uint32_t py, rt_ray* out) {
+    ray r = ray_for_pixel(c, px, py);
+    memcpy(out->origin, r.origin.v, sizeof out->origin);
+    memcpy(out->direction, r.direction.v, sizeof out->direction);
+}
+
+/* canvas.zig:42-50 — one pixel channel as toPPM prints it. */
+EXPORT int oracle_ppm_byte(float c) {
+    float v = c * 255;
+    v = fmaxf(0.0f, fminf(v, 255.0f)); /* std.math.clamp */
+    return (int)roundf(v);             /* @round: half away from zero */
+}
+
+/* ---------------------------------------------- exports for the KAT tests */
+
+EXPORT void oracle_mat_mul(const rt_mat4* a, const rt_mat4* b, rt_mat4* out) { *out = mul_matrix(*a, *b); }
+EXPORT void oracle_mat_mul_tuple(const rt_mat4* a, const float b[4], float out[4]) {
+    tuple r = mul_tuple(*a, tup_from(b));
+    memcpy(out, r.v, sizeof r.v);
+}
+EXPORT void oracle_mat_transpose(const rt_mat4* a, rt_mat4* out) { *out = transpose(*a); }
+EXPORT float oracle_mat_determinant(const rt_mat4* a) { return determinant(*a); }
+EXPORT float oracle_mat_determinant_n(const float* m, int n) {
+    matn a;
+    memset(&a, 0, sizeof a);
+    a.n = n;
+    for (int r = 0; r < n; ++r)
+        for (int c = 0; c < n; ++c) a.m[r][c] = m[r * n + c];
+    return determinant_n(a);
+}
+EXPORT float oracle_mat_cofactor_n(const float* m, int n, int row, int col) {
+    matn a;
+    memset(&a, 0, sizeof a);
+    a.n = n;
+    for (int r = 0; r < n; ++r)
+        for (int c = 0; c < n; ++c) a.m[r][c] = m[r * n + c];
+    return cofactor_n(a, row, col);
+}
+EXPORT float oracle_mat_minor_n(const float* m, int n, int row, int col) {
+    matn a;
+    memset(&a, 0, sizeof a);
+    a.n = n;
+    for (int r = 0; r < n; ++r)
+        for (int c = 0; c < n; ++c) a.m[r][c] = m[r * n + c];
+    return minor_n(a, row, col);
+}
+EXPORT void oracle_mat_inverse(const rt_mat4* a, rt_mat4* out) { *out = inverse(*a); }
+EXPORT void oracle_mat_inverse_literal(const rt_mat4* a, rt_mat4* out) { *out = inverse_literal(*a); }
+EXPORT float oracle_mat_determinant_literal(const rt_mat4* a) { return determinant_literal(*a); }
+EXPORT void oracle_mat_identity(rt_mat4* out) { *out = identity; }
+EXPORT void oracle_mat_translation(float x, float y, float z, rt_mat4* out) { *out = translation(x, y, z); }
+EXPORT void oracle_mat_scaling(float x, float y, float z, rt_mat4* out) { *out = scaling(x, y, z); }
+EXPORT void oracle_mat_rotation_x(float r, rt_mat4* out) { *out = rotation_x(r); }
+EXPORT void oracle_mat_rotation_y(float r, rt_mat4* out) { *out = rotation_y(r); }
+EXPORT void oracle_mat_rotation_z(float r, rt_mat4* out) { *out = rotation_z(r); }
+EXPORT void oracle_mat_shearing(float xy, float xz, float yx, float yz, float zx, float zy, rt_mat4* out) {
+    *out = shearing(xy, xz, yx, yz, zx, zy);
+}
+EXPORT float oracle_tup_dot(const float a[4], const float b[4]) { return dot(tup_from(a), tup_from(b)); }
+EXPORT void oracle_tup_cross(const float a[4], const float b[4], float out[4]) {
+    tuple r = cross(tup_from(a), tup_from(b));
+    memcpy(out, r.v, sizeof r.v);
+}
+EXPORT float oracle_tup_magnitude(const float a[4]) { return magnitude(tup_from(a)); }
+EXPORT void oracle_tup_normalize(const float a[4], float out[4]) {
+    tuple r = normalize(tup_from(a));
+    memcpy(out, r.v, sizeof r.v);
+}
+EXPORT void oracle_tup_reflect(const float a[4], const float n[4], float out[4]) {
+    tuple r = reflect(tup_from(a), tup_from(n));
+    memcpy(out, r.v, sizeof r.v);
+}
+EXPORT int oracle_tup_equal(const float a[4], const float b[4]) { return tup_equal(tup_from(a), tup_from(b)); }
+EXPORT int oracle_bounds_intersect(const rt_bounds* b, const rt_ray* r) {
+    ray rr = {tup_from(r->origin), tup_from(r->direction)};
+    return bounds_intersect(b, rr);
+}
+EXPORT void oracle_bounds_merge(rt_bounds* a, const rt_bounds* b) { merge_bounds(a, b); }
+EXPORT void oracle_bounds_transform(const rt_bounds* b, const rt_mat4* m, rt_bounds* out) { *out = transform_bounds(b, *m); }
+EXPORT void oracle_bound_group(const rt_group* g, rt_bounds* out) { *out = bound_group(g); }
+EXPORT float oracle_pow(float x, float y) { return m_pow(x, y); }
+EXPORT float oracle_sin(float x) { return m_sin(x); }
+EXPORT float oracle_cos(float x) { return m_cos(x); }
+EXPORT float oracle_tan(float x) { return m_tan(x); }
+
+/* triangle.zig:19-30 — Triangle.init */
+EXPORT void oracle_triangle_init(const float p0[4], const float p1[4], const float p2[4], rt_triangle* out) {
+    tuple a = tup_from(p0), b = tup_from(p1), c = tup_from(p2);
+    tuple e0 = tsub(b, a);
+    tuple e1 = tsub(c, a);
+    tuple n = normalize(cross(e1, e0));
+    memcpy(out->p0, a.v, 16);
+    memcpy(out->p1, b.v, 16);
+    memcpy(out->p2, c.v, 16);
+    memcpy(out->e0, e0.v, 16);
+    memcpy(out->e1, e1.v, 16);
+    memcpy(out->normal, n.v, 16);
+}
