@@ -1,0 +1,202 @@
+/*
+ * rtx.h — C ABI of the MI355X renderer: the flattened, device-resident form of the hot
+ * path `Camera.render -> World.colorAt`.
+ *
+ * The reference has no plugin/FFI interface; the narrowest waist its hot path sits
+ * behind is
+ *     pub fn render(allocator, cam: Camera, world: World) !Canvas   src/camera.zig:84-105
+ *     pub fn colorAt(world: *const World, r: Ray) Color             src/world.zig:81-83
+ *     pub fn rayForPixel(c: *const Camera, px, py) Ray              src/camera.zig:70-82
+ * (all paths into /root/reference).  include/rt_api.h holds the by-value drop-ins for
+ * those three; this header is the layer underneath, for callers that keep a scene
+ * resident in HBM across frames: the scene is flattened once on the host into the
+ * plain records below (precomputed inverses, composed group transforms, insertion
+ * order), uploaded with rtx_scene_create, and rendered any number of times.
+ *
+ * Conventions: every function returns 0 on success or a negative RTX_E_* code and never
+ * throws; rtx_last_error() gives the thread-local message; the caller owns every host
+ * buffer it passes; the library owns all device memory; one render in flight per
+ * rtx_scene.  Plain pointers and sizes only — no C++/torch types cross this boundary.
+ */
+#ifndef RTX_H
+#define RTX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+#pragma GCC visibility push(default) /* the exported C ABI */
+
+enum {
+    RTX_OK          = 0,
+    RTX_E_INVALID   = -1, /* bad argument / inconsistent descriptor */
+    RTX_E_NO_DEVICE = -2, /* no usable HIP device (the product path has no CPU fallback) */
+    RTX_E_HIP       = -3, /* a HIP runtime call failed; see rtx_last_error() */
+    RTX_E_NOMEM     = -4
+};
+
+/* Shape type tags, in the reference's insertion order (src/world.zig:39-44). */
+enum {
+    RTX_SPHERE = 0, RTX_PLANE = 1, RTX_CUBE = 2, RTX_CYLINDER = 3, RTX_CONE = 4, RTX_TRIANGLE = 5
+};
+
+enum {
+    RTX_SHAPE_CLOSED       = 1u << 0, /* Cylinder/Cone.closed (src/cylinder.zig:12, src/cone.zig:12) */
+    RTX_SHAPE_N1_INVISIBLE = 1u << 1  /* byte-identical twin cancels it in the n1/n2 container walk
+                                         (std.meta.eql, src/intersection.zig:104,128) */
+};
+
+/*
+ * One shape, in world-level insertion order (src/world.zig:39-45, src/group.zig:59-83):
+ * index in the array == position in the reference's stable tie-break order.
+ * `inverse` = mat.inverse(composed transform) where the composed transform is
+ * mul(mul(G_outer, G_inner), S) exactly as src/group.zig:75,103-104 composes it.
+ */
+typedef struct rtx_shape {
+    float    inverse[16]; /* row-major */
+    uint32_t type;        /* RTX_* */
+    uint32_t material;    /* index into rtx_scene_desc.materials */
+    uint32_t flags;       /* RTX_SHAPE_* */
+    uint32_t reserved;
+    float    minimum;     /* cylinder / cone */
+    float    maximum;
+    float    pad[2];
+    float    p0[4];       /* triangle (src/triangle.zig:11-17) */
+    float    e0[4];
+    float    e1[4];
+    float    normal[4];
+} rtx_shape;
+
+/* Material (src/material.zig:10-37); pattern < 0 means `pattern == null`. */
+typedef struct rtx_material {
+    float   color[3];
+    float   ambient;
+    float   diffuse;
+    float   specular;
+    float   shininess;
+    float   reflective;
+    float   refractive_index;
+    float   transparency;
+    int32_t pattern; /* index into rtx_scene_desc.patterns or -1 */
+    int32_t reserved;
+} rtx_material;
+
+/* Pattern (src/pattern.zig:14-17) with its inverse precomputed (src/pattern.zig:29). */
+typedef struct rtx_pattern {
+    float    inverse[16];
+    float    a[3];
+    float    b[3];
+    uint32_t color_map; /* RT_PATTERN_* from rt_scene.h */
+    uint32_t reserved;
+} rtx_pattern;
+
+/*
+ * One group gate (src/group.zig:55-58), in DFS order.  Node 0 is the world itself (no
+ * box).  A ray that fails a node's box skips to node index `skip` (the first node after
+ * the subtree); shapes [first_shape, first_shape + n_shapes) are the node's own members.
+ */
+typedef struct rtx_node {
+    float    bounds_min[3];
+    uint32_t has_bounds;
+    float    bounds_max[3];
+    uint32_t skip;
+    uint32_t first_shape;
+    uint32_t n_shapes;
+    uint32_t reserved[2];
+} rtx_node;
+
+typedef struct rtx_scene_desc {
+    uint32_t            n_shapes;
+    const rtx_shape*    shapes;
+    uint32_t            n_materials;
+    const rtx_material* materials;
+    uint32_t            n_patterns;
+    const rtx_pattern*  patterns;
+    uint32_t            n_nodes;
+    const rtx_node*     nodes;
+    float               light_position[4]; /* src/light.zig:5-8 */
+    float               light_intensity[3];
+    uint32_t            reserved;
+} rtx_scene_desc;
+
+/* Camera with its inverse precomputed on the host (src/camera.zig:17-23,77-78). */
+typedef struct rtx_camera {
+    uint32_t horizontal_size;
+    uint32_t vertical_size;
+    float    half_width;
+    float    half_height;
+    float    pixel_size;
+    float    inverse_transform[16];
+} rtx_camera;
+
+typedef struct rtx_opts {
+    uint32_t depth;        /* ray_depth_limit, src/world.zig:20; 0 means the default 5; max 5 */
+    uint32_t rows_quirk;   /* 1: render only 8*floor(H/8) rows, the rest stay black (src/camera.zig:87-88) */
+    uint32_t batch_pixels; /* pixels per wavefront batch; 0 = default */
+    /* Row-strip sharding for one-process-per-GPU runs: this call renders the strips
+     * s with s % strip_count == strip_index, a strip being strip_rows consecutive rows.
+     * strip_count <= 1 renders the whole frame.  Output rows keep their place in the
+     * full canvas unless compact_rows != 0 (then the rendered rows are packed in order). */
+    uint32_t strip_rows;
+    uint32_t strip_count;
+    uint32_t strip_index;
+    uint32_t compact_rows;
+    uint32_t profile;      /* 1: time each kernel class with HIP events (adds syncs) */
+} rtx_opts;
+
+typedef struct rtx_stats {
+    uint64_t rays_primary;   /* colorAtInternal calls at the root (src/world.zig:85) */
+    uint64_t rays_shadow;    /* isShadowed calls (src/world.zig:97) */
+    uint64_t rays_secondary; /* colorAtInternal calls below the root */
+    uint64_t level_rays[6];  /* rays traced per depth level */
+    uint64_t nodes;          /* interior ray-tree nodes stored for the combine pass */
+    float    ms_total;       /* device time of the whole call (HIP events on the render stream) */
+    float    ms_trace_shade; /* sum over launches of the trace+shade kernel (profile=1) */
+    float    ms_combine;     /* sum over launches of the combine kernel (profile=1) */
+    uint32_t launches_trace_shade;
+    uint32_t launches_combine;
+    uint32_t rows_rendered;
+    uint32_t reserved;
+} rtx_stats;
+
+typedef struct rtx_scene rtx_scene; /* opaque; owns the device copies */
+
+/* Number of HIP devices visible, or a negative RTX_E_* code. */
+int rtx_device_count(void);
+
+/* Validate and upload a flattened scene to `device`. */
+int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out);
+void rtx_scene_destroy(rtx_scene* scene);
+
+/* Rows rtx_render would produce for these options (compact_rows layout). */
+int rtx_rows_for(const rtx_camera* cam, const rtx_opts* opts, uint32_t* n_rows);
+
+/*
+ * render() — src/camera.zig:84-105.  Fills `rgb_out` (caller-owned host memory,
+ * H*W*3 f32 row-major like Canvas.pixels, src/canvas.zig:15-28,52-54; or
+ * n_rows*W*3 when compact_rows) — blocking.  `opts` and `stats` may be NULL.
+ */
+int rtx_render(rtx_scene* scene, const rtx_camera* cam, const rtx_opts* opts, float* rgb_out, rtx_stats* stats);
+
+/*
+ * Same, but the canvas stays on the device: `d_rgb_out` is a device pointer of the same
+ * shape, `stream` a hipStream_t (NULL = the library's own stream).  The call returns after
+ * the work is enqueued and stats (if requested) are read back, i.e. it synchronises only
+ * when `stats` is non-NULL.  `d_rgb8_out`, if non-NULL, also receives the canvas quantised
+ * as canvas.zig:45-47 does (round(clamp(c*255, 0, 255)) as u8, 3 bytes per pixel).
+ */
+int rtx_render_device(rtx_scene* scene, const rtx_camera* cam, const rtx_opts* opts, void* d_rgb_out,
+                      void* d_rgb8_out, void* stream, rtx_stats* stats);
+
+/* colorAt() — src/world.zig:81-83 — for n rays (origins/directions: n*4 f32; rgb: n*3 f32), host buffers. */
+int rtx_color_at(rtx_scene* scene, const float* origins, const float* directions, uint32_t n, uint32_t depth,
+                 float* rgb_out);
+
+const char* rtx_last_error(void);
+
+#pragma GCC visibility pop
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTX_H */

@@ -28,6 +28,7 @@ static rt_material default_material(void) { /* material.zig:10-37 */
     memset(&m, 0, sizeof m);
     m.color[0] = m.color[1] = m.color[2] = 1;
     m.has_pattern = 0;
+    m.pattern.transform = identity; /* payload of a null optional: unused */
     m.ambient = 0.1f;
     m.diffuse = 0.9f;
     m.specular = 0.9f;

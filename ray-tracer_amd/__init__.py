@@ -1,0 +1,307 @@
+"""ray-tracer_amd — MI355X-native renderer for the hot path `Camera.render -> World.colorAt`.
+
+This package is a thin ctypes binding over the C ABI of libraytracer_amd.so
+(include/rt_api.h, include/rtx.h): the product is the shared library (HIP kernels + C++
+host side); Python only moves pointers.  Import with
+    rta = importlib.import_module("ray-tracer_amd")
+(the directory name carries the reference's hyphen).
+
+There is no CPU fallback: rendering entry points raise RtxError when the HIP library or a
+GPU is missing.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import scene_types as st
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libraytracer_amd.so")
+
+f32 = C.c_float
+u32 = C.c_uint32
+P = C.POINTER
+
+
+class RtxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("rtx error %d: %s" % (code, msg))
+        self.code = code
+
+
+class RtxShape(C.Structure):
+    _fields_ = [("inverse", f32 * 16), ("type", u32), ("material", u32), ("flags", u32), ("reserved", u32),
+                ("minimum", f32), ("maximum", f32), ("pad", f32 * 2),
+                ("p0", f32 * 4), ("e0", f32 * 4), ("e1", f32 * 4), ("normal", f32 * 4)]
+
+
+class RtxMaterial(C.Structure):
+    _fields_ = [("color", f32 * 3), ("ambient", f32), ("diffuse", f32), ("specular", f32), ("shininess", f32),
+                ("reflective", f32), ("refractive_index", f32), ("transparency", f32),
+                ("pattern", C.c_int32), ("reserved", C.c_int32)]
+
+
+class RtxPattern(C.Structure):
+    _fields_ = [("inverse", f32 * 16), ("a", f32 * 3), ("b", f32 * 3), ("color_map", u32), ("reserved", u32)]
+
+
+class RtxNode(C.Structure):
+    _fields_ = [("bounds_min", f32 * 3), ("has_bounds", u32), ("bounds_max", f32 * 3), ("skip", u32),
+                ("first_shape", u32), ("n_shapes", u32), ("reserved", u32 * 2)]
+
+
+class RtxSceneDesc(C.Structure):
+    _fields_ = [("n_shapes", u32), ("shapes", P(RtxShape)),
+                ("n_materials", u32), ("materials", P(RtxMaterial)),
+                ("n_patterns", u32), ("patterns", P(RtxPattern)),
+                ("n_nodes", u32), ("nodes", P(RtxNode)),
+                ("light_position", f32 * 4), ("light_intensity", f32 * 3), ("reserved", u32)]
+
+
+class RtxCamera(C.Structure):
+    _fields_ = [("horizontal_size", u32), ("vertical_size", u32), ("half_width", f32), ("half_height", f32),
+                ("pixel_size", f32), ("inverse_transform", f32 * 16)]
+
+
+class RtxOpts(C.Structure):
+    _fields_ = [("depth", u32), ("rows_quirk", u32), ("batch_pixels", u32), ("strip_rows", u32),
+                ("strip_count", u32), ("strip_index", u32), ("compact_rows", u32), ("profile", u32)]
+
+
+class RtxStats(C.Structure):
+    _fields_ = [("rays_primary", C.c_uint64), ("rays_shadow", C.c_uint64), ("rays_secondary", C.c_uint64),
+                ("level_rays", C.c_uint64 * 6), ("nodes", C.c_uint64),
+                ("ms_total", f32), ("ms_trace_shade", f32), ("ms_combine", f32),
+                ("launches_trace_shade", u32), ("launches_combine", u32), ("rows_rendered", u32), ("reserved", u32)]
+
+    @property
+    def rays_total(self):
+        return self.rays_primary + self.rays_shadow + self.rays_secondary
+
+
+# Every symbol include/rt_api.h and include/rtx.h declare: (name, restype, argtypes).
+_SIGNATURES = [
+    ("rtx_device_count", C.c_int, []),
+    ("rtx_scene_create", C.c_int, [P(RtxSceneDesc), C.c_int, P(C.c_void_p)]),
+    ("rtx_scene_destroy", None, [C.c_void_p]),
+    ("rtx_rows_for", C.c_int, [P(RtxCamera), P(RtxOpts), P(u32)]),
+    ("rtx_render", C.c_int, [C.c_void_p, P(RtxCamera), P(RtxOpts), P(f32), P(RtxStats)]),
+    ("rtx_render_device", C.c_int, [C.c_void_p, P(RtxCamera), P(RtxOpts), C.c_void_p, C.c_void_p, C.c_void_p, P(RtxStats)]),
+    ("rtx_color_at", C.c_int, [C.c_void_p, P(f32), P(f32), u32, u32, P(f32)]),
+    ("rtx_last_error", C.c_char_p, []),
+    ("rt_camera_init", None, [u32, u32, f32, P(f32), P(f32), P(f32), P(st.Camera)]),
+    ("rt_ray_for_pixel", None, [P(st.Camera), u32, u32, P(st.Ray)]),
+    ("rt_render", C.c_int, [P(st.Camera), P(st.World), P(f32), P(st.RayCounts)]),
+    ("rt_color_at", C.c_int, [P(st.World), P(st.Ray), u32, P(f32)]),
+    ("rt_canvas_to_ppm", C.c_uint64, [P(f32), u32, u32, C.c_char_p, C.c_uint64]),
+    ("rt_ppm_byte", C.c_int, [f32]),
+    ("rt_flatten", C.c_int, [P(st.World), P(C.c_void_p)]),
+    ("rt_flat_desc", P(RtxSceneDesc), [C.c_void_p]),
+    ("rt_flat_free", None, [C.c_void_p]),
+    ("rt_flatten_camera", None, [P(st.Camera), P(RtxCamera)]),
+    ("rt_triangle_init", None, [P(f32), P(f32), P(f32), P(st.Triangle)]),
+    ("rt_bound_group", None, [P(st.Group), P(st.Bounds)]),
+    ("rt_bounds_intersect", C.c_int, [P(st.Bounds), P(st.Ray)]),
+    ("rt_bounds_merge", None, [P(st.Bounds), P(st.Bounds)]),
+    ("rt_bounds_transform", None, [P(st.Bounds), P(st.Mat4), P(st.Bounds)]),
+    ("rt_default_material", None, [P(st.Material)]),
+    ("rt_default_attrs", None, [P(st.Attrs)]),
+    ("rt_mat_identity", None, [P(st.Mat4)]),
+    ("rt_mat_mul", None, [P(st.Mat4), P(st.Mat4), P(st.Mat4)]),
+    ("rt_mat_mul_tuple", None, [P(st.Mat4), P(f32), P(f32)]),
+    ("rt_mat_transpose", None, [P(st.Mat4), P(st.Mat4)]),
+    ("rt_mat_determinant", f32, [P(st.Mat4)]),
+    ("rt_mat_determinant_n", f32, [P(f32), C.c_int]),
+    ("rt_mat_minor_n", f32, [P(f32), C.c_int, C.c_int, C.c_int]),
+    ("rt_mat_cofactor_n", f32, [P(f32), C.c_int, C.c_int, C.c_int]),
+    ("rt_mat_inverse", None, [P(st.Mat4), P(st.Mat4)]),
+    ("rt_mat_translation", None, [f32, f32, f32, P(st.Mat4)]),
+    ("rt_mat_scaling", None, [f32, f32, f32, P(st.Mat4)]),
+    ("rt_mat_rotation_x", None, [f32, P(st.Mat4)]),
+    ("rt_mat_rotation_y", None, [f32, P(st.Mat4)]),
+    ("rt_mat_rotation_z", None, [f32, P(st.Mat4)]),
+    ("rt_mat_shearing", None, [f32, f32, f32, f32, f32, f32, P(st.Mat4)]),
+    ("rt_tup_dot", f32, [P(f32), P(f32)]),
+    ("rt_tup_cross", None, [P(f32), P(f32), P(f32)]),
+    ("rt_tup_magnitude", f32, [P(f32)]),
+    ("rt_tup_normalize", None, [P(f32), P(f32)]),
+    ("rt_tup_reflect", None, [P(f32), P(f32), P(f32)]),
+    ("rt_tup_equal", C.c_int, [P(f32), P(f32)]),
+    ("rt_pow", f32, [f32, f32]),
+    ("rt_sin", f32, [f32]),
+    ("rt_cos", f32, [f32]),
+    ("rt_tan", f32, [f32]),
+    ("rt_sample_create", C.c_void_p, [C.c_char_p, u32, u32]),
+    ("rt_sample_world", P(st.World), [C.c_void_p]),
+    ("rt_sample_camera", P(st.Camera), [C.c_void_p]),
+    ("rt_sample_destroy", None, [C.c_void_p]),
+]
+
+SYMBOLS = [s[0] for s in _SIGNATURES]
+
+_lib = None
+
+
+def build():
+    """Compile libraytracer_amd.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    subprocess.check_call(["make", "-s", "-C", HERE, "-j8"])
+
+
+def lib():
+    """Load the shared library; fails loudly if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RtxError(-2, "%s is missing: run `make -C ray-tracer_amd` (or __graft_entry__.build())" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    for name, restype, argtypes in _SIGNATURES:
+        fn = getattr(L, name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise RtxError(rc, lib().rtx_last_error().decode(errors="replace"))
+
+
+def fptr(a):
+    return a.ctypes.data_as(P(f32))
+
+
+class Sample:
+    """One of the reference's sample scenes (samples/<name>.zig) built by the C++ mirror."""
+
+    def __init__(self, name, width=0, height=0):
+        L = lib()
+        self.name = name
+        self.handle = L.rt_sample_create(name.encode(), width, height)
+        if not self.handle:
+            raise KeyError(name)
+        self.world = L.rt_sample_world(self.handle).contents
+        self.camera = L.rt_sample_camera(self.handle).contents
+
+    def __del__(self):
+        if getattr(self, "handle", None):
+            lib().rt_sample_destroy(self.handle)
+            self.handle = None
+
+
+SAMPLES = ["sphere_world", "glass_spheres", "fresnel", "cylinder_world", "cone", "cube", "reflective_floor",
+           "skewed_triangle", "striped_scene", "sphere_on_plane"]
+
+
+def camera(hsize, vsize, fov, frm, to, up):
+    """camera() — src/camera.zig:25-51."""
+    c = st.Camera()
+    a = [(f32 * 4)(*v) for v in (frm, to, up)]
+    lib().rt_camera_init(hsize, vsize, fov, a[0], a[1], a[2], C.byref(c))
+    return c
+
+
+def flatten_camera(cam):
+    out = RtxCamera()
+    lib().rt_flatten_camera(C.byref(cam), C.byref(out))
+    return out
+
+
+class FlatScene:
+    """Host-side flattened scene (rt_flatten): owns the arrays of an rtx_scene_desc."""
+
+    def __init__(self, world):
+        h = C.c_void_p()
+        _check(lib().rt_flatten(C.byref(world), C.byref(h)))
+        self.handle = h
+        self.desc = lib().rt_flat_desc(h).contents
+
+    def __del__(self):
+        if getattr(self, "handle", None):
+            lib().rt_flat_free(self.handle)
+            self.handle = None
+
+
+class Scene:
+    """A scene resident on one GPU (rtx_scene)."""
+
+    def __init__(self, world, device=0):
+        flat = FlatScene(world)
+        h = C.c_void_p()
+        _check(lib().rtx_scene_create(C.byref(flat.desc), device, C.byref(h)))
+        self.handle = h
+        self.n_shapes = flat.desc.n_shapes
+
+    def close(self):
+        if getattr(self, "handle", None):
+            lib().rtx_scene_destroy(self.handle)
+            self.handle = None
+
+    __del__ = close
+
+    def render(self, cam, rows_quirk=True, depth=0, batch_pixels=0, strips=None, compact_rows=False, profile=False):
+        """render() — src/camera.zig:84-105 -> (canvas float32 [rows, W, 3], RtxStats)."""
+        L = lib()
+        rc = flatten_camera(cam) if isinstance(cam, st.Camera) else cam
+        opts = RtxOpts(depth=depth, rows_quirk=1 if rows_quirk else 0, batch_pixels=batch_pixels,
+                       compact_rows=1 if compact_rows else 0, profile=1 if profile else 0)
+        if strips is not None:
+            opts.strip_rows, opts.strip_count, opts.strip_index = strips
+        rows = u32()
+        _check(L.rtx_rows_for(C.byref(rc), C.byref(opts), C.byref(rows)))
+        h = rows.value if compact_rows else rc.vertical_size
+        canvas = np.zeros((h, rc.horizontal_size, 3), dtype=np.float32)
+        stats = RtxStats()
+        _check(L.rtx_render(self.handle, C.byref(rc), C.byref(opts), fptr(canvas), C.byref(stats)))
+        return canvas, stats
+
+    def render_device(self, cam, d_rgb, d_rgb8=None, stream=None, want_stats=False, **kw):
+        """rtx_render_device: canvas stays on the GPU (d_rgb / d_rgb8 are raw device pointers)."""
+        L = lib()
+        rc = flatten_camera(cam) if isinstance(cam, st.Camera) else cam
+        opts = RtxOpts(depth=kw.get("depth", 0), rows_quirk=1 if kw.get("rows_quirk", True) else 0,
+                       batch_pixels=kw.get("batch_pixels", 0), compact_rows=1 if kw.get("compact_rows", False) else 0,
+                       profile=1 if kw.get("profile", False) else 0)
+        if kw.get("strips") is not None:
+            opts.strip_rows, opts.strip_count, opts.strip_index = kw["strips"]
+        stats = RtxStats() if want_stats else None
+        _check(L.rtx_render_device(self.handle, C.byref(rc), C.byref(opts), C.c_void_p(d_rgb),
+                                   C.c_void_p(d_rgb8) if d_rgb8 else None, C.c_void_p(stream) if stream else None,
+                                   C.byref(stats) if stats is not None else None))
+        return stats
+
+    def color_at(self, origins, directions, depth=0):
+        """colorAt() — src/world.zig:81-83 for n rays -> float32 [n, 3]."""
+        o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 4)
+        d = np.ascontiguousarray(directions, dtype=np.float32).reshape(-1, 4)
+        out = np.zeros((o.shape[0], 3), dtype=np.float32)
+        _check(lib().rtx_color_at(self.handle, fptr(o), fptr(d), o.shape[0], depth, fptr(out)))
+        return out
+
+
+def rows_for(cam, strips=None, rows_quirk=True):
+    rc = flatten_camera(cam) if isinstance(cam, st.Camera) else cam
+    opts = RtxOpts(rows_quirk=1 if rows_quirk else 0)
+    if strips is not None:
+        opts.strip_rows, opts.strip_count, opts.strip_index = strips
+    rows = u32()
+    _check(lib().rtx_rows_for(C.byref(rc), C.byref(opts), C.byref(rows)))
+    return rows.value
+
+
+def render(cam, world):
+    """The by-value drop-in rt_render (flatten + upload + render + copy back)."""
+    canvas = np.zeros((cam.vertical_size, cam.horizontal_size, 3), dtype=np.float32)
+    counts = st.RayCounts()
+    _check(lib().rt_render(C.byref(cam), C.byref(world), fptr(canvas), C.byref(counts)))
+    return canvas, counts
+
+
+def to_ppm_bytes(canvas):
+    """canvas.zig:45-47 per channel through the library's rt_ppm_byte rule (vectorised)."""
+    v = canvas.astype(np.float32) * np.float32(255)
+    v = np.maximum(np.float32(0), np.minimum(v, np.float32(255)))
+    return np.floor(v.astype(np.float64) + 0.5).astype(np.uint8)

@@ -1,0 +1,1276 @@
+// rtx_device.hip — the hot path `Camera.render -> World.colorAt` as a wavefront pipeline of
+// hand-written HIP kernels for gfx950 (MI355X), behind the C ABI of include/rtx.h.
+//
+// Pipeline per batch of pixels (all launches asynchronous on one stream, no host syncs):
+//
+//   k_trace_shade  level 0..depth   one launch per ray-tree level.  Level 0 generates the
+//                                    camera rays (rayForPixel); deeper levels read the
+//                                    compacted ray queue the previous level wrote.  Per ray:
+//                                    closest hit over the flattened shape list (group gates
+//                                    included), prepareComputations, shadow any-hit, Phong,
+//                                    Schlick, and the <=2 child rays pushed to the next
+//                                    level's queue with wave-aggregated atomics.
+//   k_combine      level depth-1..0  bottom-up: interior ray-tree nodes evaluate
+//                                    surface + reflected*R + refracted*(1-R) in the
+//                                    reference's order and hand the result to their parent
+//                                    slot (or the canvas at the root).
+//
+// Every pixel's colour is produced by exactly the reference's f32 operations in the
+// reference's order (no float atomics, no reassociation), so the canvas is bit-reproducible
+// and independent of batch size, launch geometry and GPU count.
+//
+// Compile with -ffp-contract=off (explicit fmaf only where the reference uses @mulAdd), no
+// fast-math, correctly rounded f32 divide/sqrt (hipcc default).
+//
+// Reference citations are file:line into /root/reference.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/rt_scene.h"
+#include "../../include/rtx.h"
+#include "../host/rt_libm.hpp"
+
+namespace {
+
+// ------------------------------------------------------------------------- errors
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) return fail(RTX_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+// ------------------------------------------------------------------- device records
+
+constexpr float kEpsilon = 0.00001f;  // src/tuple.zig:10
+constexpr uint32_t kNone = 0xFFFFFFFFu;
+constexpr uint32_t kLinkIndexMask = 0x3FFFFFFFu;
+constexpr uint32_t kLinkSlotBit = 1u << 30;    // 0: reflected slot, 1: refracted slot
+constexpr uint32_t kLinkSchlickBit = 1u << 31; // node combines with Schlick reflectance
+constexpr int kMaxDepth = 5;                   // src/world.zig:20
+constexpr int kLevels = kMaxDepth + 1;
+
+struct V4 {
+    float x, y, z, w;
+};
+
+struct Counters {
+    uint32_t queue_count[kLevels + 1];  // rays queued for level d (level 0 is implicit)
+    uint32_t node_count[kLevels];       // interior nodes allocated at level d
+    uint32_t hits[kLevels];             // hits at level d == isShadowed calls
+    uint32_t pad;
+};
+
+struct Totals {
+    unsigned long long level_rays[kLevels];
+    unsigned long long hits;
+    unsigned long long nodes;
+};
+
+struct Params {
+    const rtx_shape* shapes;
+    const rtx_node* nodes;
+    const rtx_material* materials;
+    const rtx_pattern* patterns;
+    uint32_t n_nodes;
+    uint32_t n_shapes;
+    uint32_t track_n1;  // scene has a transparent material: track the n1 predecessor
+    uint32_t depth;
+    float light_position[4];
+    float light_intensity[3];
+    float over_eps;  // tup.epsilon * 100.0 as an f32 product (src/world.zig:55)
+
+    // camera (src/camera.zig:17-23 with the inverse hoisted, :77-78)
+    float cam_inv[16];
+    float half_width, half_height, pixel_size;
+    uint32_t width;
+
+    // this batch: local rows [row0, row0 + n_rows) of the rows this call renders
+    uint32_t row0, n_rows, tiles_x;
+    uint32_t strip_rows, strip_count, strip_index, compact_rows;
+
+    // ray queues (ping-pong by level parity) and ray-tree nodes
+    float4* q_org[2];
+    float4* q_dir[2];
+    uint2* q_link[2];
+    float4* node_a;  // surface.rgb, reflectance
+    float4* node_b;  // reflected slot rgb, weight towards the parent
+    float4* node_c;  // refracted slot rgb, link bits
+    uint32_t node_off[kLevels];
+
+    Counters* counters;
+    float* canvas;        // root results land here: 3 floats per root index
+    uint32_t root_count;  // level-0 work items when rays come from the queue (rtx_color_at)
+};
+
+// ------------------------------------------------------------------------ f32 math
+
+__device__ __forceinline__ V4 v4(float x, float y, float z, float w) { return V4{x, y, z, w}; }
+__device__ __forceinline__ V4 add(V4 a, V4 b) { return v4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ V4 sub(V4 a, V4 b) { return v4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ V4 muls(V4 a, float s) { return v4(a.x * s, a.y * s, a.z * s, a.w * s); }
+__device__ __forceinline__ V4 divs(V4 a, float s) { return v4(a.x / s, a.y / s, a.z / s, a.w / s); }
+__device__ __forceinline__ V4 neg(V4 a) { return v4(-a.x, -a.y, -a.z, -a.w); }
+
+// tup.dot — four lanes, left to right (src/tuple.zig:38-40)
+__device__ __forceinline__ float dot(V4 u, V4 v) { return u.x * v.x + u.y * v.y + u.z * v.z + u.w * v.w; }
+// tup.cross — w lane 0 (src/tuple.zig:42-48)
+__device__ __forceinline__ V4 cross(V4 u, V4 v) {
+    return v4(u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x, 0.0f);
+}
+__device__ __forceinline__ float magnitude(V4 v) { return sqrtf(dot(v, v)); }          // tuple.zig:50-52
+__device__ __forceinline__ V4 normalize(V4 v) { return divs(v, magnitude(v)); }        // tuple.zig:54-56
+__device__ __forceinline__ V4 reflect(V4 incident, V4 normal) {                        // tuple.zig:58-77
+    return sub(incident, muls(muls(normal, dot(incident, normal)), 2.0f));
+}
+
+// mat.mulTuple (src/matrix.zig:62-64) with a row-major 16-float matrix.
+__device__ __forceinline__ V4 mul_mat(const float* m, V4 b) {
+    return v4(m[0] * b.x + m[1] * b.y + m[2] * b.z + m[3] * b.w, m[4] * b.x + m[5] * b.y + m[6] * b.z + m[7] * b.w,
+              m[8] * b.x + m[9] * b.y + m[10] * b.z + m[11] * b.w,
+              m[12] * b.x + m[13] * b.y + m[14] * b.z + m[15] * b.w);
+}
+// mat.mul(mat.transpose(m), b) (src/matrix.zig:74-87 then :62-64)
+__device__ __forceinline__ V4 mul_mat_t(const float* m, V4 b) {
+    return v4(m[0] * b.x + m[4] * b.y + m[8] * b.z + m[12] * b.w, m[1] * b.x + m[5] * b.y + m[9] * b.z + m[13] * b.w,
+              m[2] * b.x + m[6] * b.y + m[10] * b.z + m[14] * b.w,
+              m[3] * b.x + m[7] * b.y + m[11] * b.z + m[15] * b.w);
+}
+
+// std.math.approxEqAbs(f32, x, 0, eps)
+__device__ __forceinline__ bool approx_zero(float x) {
+    if (x == 0.0f) return true;
+    if (x != x) return false;
+    return fabsf(x) <= kEpsilon;
+}
+
+// ------------------------------------------------------------------- intersections
+
+// Closest hit and, when the scene has a transparent material, the n1 predecessor.
+//
+// The reference appends every root to one list, stable-sorts it by t and takes the first
+// t >= 0 (src/world.zig:38-47, src/intersection.zig:14-28): that is the minimum t >= 0
+// with ties going to the earlier insertion — a strict `<` while visiting shapes in
+// insertion order.  Its n1/n2 container walk compares whole intersections including t
+// (std.meta.eql, src/intersection.zig:104,128), so an exit never removes its entry: n1 is
+// the refractive index of the entry just before the hit in the sorted list, i.e. the
+// largest t < 0 with ties going to the LATER insertion (`>=`), or 1.0 if none; n2 is the
+// hit shape's own index.  Exactly equal (t, shape) entries toggle each other out of the
+// walk, hence the same-shape duplicate cancelling below and RTX_SHAPE_N1_INVISIBLE.
+struct Closest {
+    float t;
+    uint32_t idx;
+    float pred_t;
+    uint32_t pred_idx;
+};
+
+template <bool TRACK>
+struct ClosestVisitor {
+    Closest c;
+    __device__ __forceinline__ void init() {
+        c.t = 0.0f;
+        c.idx = kNone;
+        c.pred_t = 0.0f;
+        c.pred_idx = kNone;
+    }
+    __device__ __forceinline__ void hit(float t, uint32_t s) {
+        if (t >= 0.0f && (c.idx == kNone || t < c.t)) {
+            c.t = t;
+            c.idx = s;
+        }
+    }
+    __device__ __forceinline__ void pred(float t, uint32_t s) {
+        if (TRACK && t < 0.0f && (c.pred_idx == kNone || t >= c.pred_t)) {
+            c.pred_t = t;
+            c.pred_idx = s;
+        }
+    }
+    static constexpr bool kTrack = TRACK;
+    __device__ __forceinline__ bool done() const { return false; }
+};
+
+// isShadowed (src/world.zig:97-120): the nearest t >= 0 is < distance  <=>  some root lies
+// in [0, distance).
+struct ShadowVisitor {
+    float distance;
+    bool found;
+    __device__ __forceinline__ void hit(float t, uint32_t) {
+        if (t >= 0.0f && t < distance) found = true;
+    }
+    __device__ __forceinline__ void pred(float, uint32_t) {}
+    static constexpr bool kTrack = false;
+    __device__ __forceinline__ bool done() const { return found; }
+};
+
+struct TMinMax {
+    float tmin, tmax;
+};
+
+// checkAxis (src/cube.zig:52-67 with min/max = -1/1, src/bounds.zig:160-175)
+__device__ __forceinline__ TMinMax check_axis(float mn, float mx, float origin, float direction) {
+    const float tmin_numerator = mn - origin;
+    const float tmax_numerator = mx - origin;
+    float tmin, tmax;
+    if (fabsf(direction) >= kEpsilon) {
+        tmin = tmin_numerator / direction;
+        tmax = tmax_numerator / direction;
+    } else {
+        tmin = tmin_numerator * INFINITY;
+        tmax = tmax_numerator * INFINITY;
+    }
+    if (tmin > tmax) return TMinMax{tmax, tmin};
+    return TMinMax{tmin, tmax};
+}
+
+// bnd.intersect (src/bounds.zig:149-158): infinite-line slab test, no t range.
+__device__ __forceinline__ bool bounds_hit(const rtx_node& n, V4 o, V4 d) {
+    const TMinMax x = check_axis(n.bounds_min[0], n.bounds_max[0], o.x, d.x);
+    const TMinMax y = check_axis(n.bounds_min[1], n.bounds_max[1], o.y, d.y);
+    const TMinMax z = check_axis(n.bounds_min[2], n.bounds_max[2], o.z, d.z);
+    const float tmin = fmaxf(x.tmin, fmaxf(y.tmin, z.tmin));
+    const float tmax = fminf(x.tmax, fminf(y.tmax, z.tmax));
+    return tmin <= tmax;
+}
+
+// Offer up to four roots of one shape.  For the predecessor, roots of the same shape with
+// exactly equal t cancel pairwise (they are equal Intersections in the container walk).
+template <class V>
+__device__ __forceinline__ void offer_roots(V& v, uint32_t s, bool n1_visible, const float* t, const bool* ok) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (ok[i]) v.hit(t[i], s);
+    if (V::kTrack && n1_visible) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (!ok[i]) continue;
+            int same = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (ok[j] && t[j] == t[i]) ++same;
+            if (same & 1) v.pred(t[i], s);
+        }
+    }
+}
+
+// Shape.intersect for every shape type; `sh` is wave-uniform (scalar loads), the ray is
+// per lane.  o/d are the world-space ray; the object-space ray is r.transform(inverse)
+// (src/ray.zig:13-18) with all four lanes kept.
+template <class V>
+__device__ __forceinline__ void intersect_shape(V& v, const rtx_shape& sh, uint32_t s, V4 o, V4 d) {
+    const V4 ro = mul_mat(sh.inverse, o);
+    const V4 rd = mul_mat(sh.inverse, d);
+    const bool n1_visible = !(sh.flags & RTX_SHAPE_N1_INVISIBLE);
+    float t[4];
+    bool ok[4] = {false, false, false, false};
+
+    switch (sh.type) {
+    case RTX_SPHERE: {  // src/sphere.zig:11-54
+        const V4 sphere_to_ray = sub(ro, v4(0.0f, 0.0f, 0.0f, 1.0f));
+        const float a = dot(rd, rd);
+        const float b = 2.0f * dot(rd, sphere_to_ray);
+        const float c = dot(sphere_to_ray, sphere_to_ray) - 1.0f;
+        const float discriminant = b * b - 4.0f * a * c;
+        if (discriminant >= 0.0f) {
+            const float sq = sqrtf(discriminant);
+            t[0] = (-b - sq) / (2.0f * a);
+            t[1] = (-b + sq) / (2.0f * a);
+            ok[0] = ok[1] = true;
+        }
+        break;
+    }
+    case RTX_PLANE: {  // src/plane.zig:13-28
+        if (!(fabsf(rd.y) < kEpsilon)) {
+            t[0] = -ro.y / rd.y;
+            ok[0] = true;
+        }
+        break;
+    }
+    case RTX_CUBE: {  // src/cube.zig:11-26
+        const TMinMax x = check_axis(-1.0f, 1.0f, ro.x, rd.x);
+        const TMinMax y = check_axis(-1.0f, 1.0f, ro.y, rd.y);
+        const TMinMax z = check_axis(-1.0f, 1.0f, ro.z, rd.z);
+        const float tmin = fmaxf(x.tmin, fmaxf(y.tmin, z.tmin));
+        const float tmax = fminf(x.tmax, fminf(y.tmax, z.tmax));
+        if (!(tmin > tmax)) {
+            t[0] = tmin;
+            t[1] = tmax;
+            ok[0] = ok[1] = true;
+        }
+        break;
+    }
+    case RTX_CYLINDER:  // src/cylinder.zig:14-71
+    case RTX_CONE: {    // src/cone.zig:14-82
+        const bool cone = sh.type == RTX_CONE;
+        float a, b, c;
+        if (cone) {
+            a = rd.x * rd.x - rd.y * rd.y + rd.z * rd.z;
+            b = 2.0f * ro.x * rd.x - 2.0f * ro.y * rd.y + 2.0f * ro.z * rd.z;
+            c = ro.x * ro.x - ro.y * ro.y + ro.z * ro.z;
+        } else {
+            a = rd.x * rd.x + rd.z * rd.z;
+            b = 2.0f * ro.x * rd.x + 2.0f * ro.z * rd.z;
+            c = ro.x * ro.x + ro.z * ro.z - 1.0f;
+        }
+        bool walls = true;
+        if (approx_zero(a)) {
+            walls = false;
+            if (cone && !approx_zero(b)) {  // src/cone.zig:35-39: the single root
+                t[0] = -c / (2.0f * b);
+                ok[0] = true;
+            }
+        }
+        if (walls) {
+            const float discriminant = b * b - 4.0f * a * c;
+            if (!(discriminant < 0.0f)) {
+                const float sq = sqrtf(discriminant);
+                float t0 = (-b - sq) / (2.0f * a);
+                float t1 = (-b + sq) / (2.0f * a);
+                if (t0 > t1) {
+                    const float tmp = t0;
+                    t0 = t1;
+                    t1 = tmp;
+                }
+                const float y0 = fmaf(t0, rd.y, ro.y);  // @mulAdd, cylinder.zig:40 / cone.zig:53
+                if (sh.minimum < y0 && y0 < sh.maximum) {
+                    t[0] = t0;
+                    ok[0] = true;
+                }
+                const float y1 = fmaf(t1, rd.y, ro.y);  // @mulAdd, cylinder.zig:45 / cone.zig:58
+                if (sh.minimum < y1 && y1 < sh.maximum) {
+                    t[1] = t1;
+                    ok[1] = true;
+                }
+            }
+        }
+        // intersectCaps (src/cylinder.zig:53-71, src/cone.zig:66-82)
+        if ((sh.flags & RTX_SHAPE_CLOSED) && !approx_zero(rd.y)) {
+            const float t_lower = (sh.minimum - ro.y) / rd.y;
+            {
+                const float x = fmaf(t_lower, rd.x, ro.x);  // checkCap, cylinder.zig:98-99 / cone.zig:111-112
+                const float z = fmaf(t_lower, rd.z, ro.z);
+                const float limit = cone ? fabsf(sh.minimum * sh.minimum) : 1.0f;
+                if ((x * x + z * z) <= limit) {
+                    t[2] = t_lower;
+                    ok[2] = true;
+                }
+            }
+            const float t_upper = (sh.maximum - ro.y) / rd.y;
+            {
+                const float x = fmaf(t_upper, rd.x, ro.x);
+                const float z = fmaf(t_upper, rd.z, ro.z);
+                const float limit = cone ? fabsf(sh.maximum * sh.maximum) : 1.0f;
+                if ((x * x + z * z) <= limit) {
+                    t[3] = t_upper;
+                    ok[3] = true;
+                }
+            }
+        }
+        break;
+    }
+    default: {  // RTX_TRIANGLE, src/triangle.zig:32-50 (Moller-Trumbore)
+        const V4 e0 = v4(sh.e0[0], sh.e0[1], sh.e0[2], sh.e0[3]);
+        const V4 e1 = v4(sh.e1[0], sh.e1[1], sh.e1[2], sh.e1[3]);
+        const V4 p0 = v4(sh.p0[0], sh.p0[1], sh.p0[2], sh.p0[3]);
+        const V4 dir_cross_e1 = cross(rd, e1);
+        const float det = dot(e0, dir_cross_e1);
+        if (!(fabsf(det) < kEpsilon)) {
+            const float f = 1.0f / det;
+            const V4 p0_to_origin = sub(ro, p0);
+            const float u = f * dot(p0_to_origin, dir_cross_e1);
+            if (!(u < 0.0f || u > 1.0f)) {
+                const V4 origin_cross_e0 = cross(p0_to_origin, e0);
+                const float vv = f * dot(rd, origin_cross_e0);
+                if (!(vv < 0.0f || (u + vv) > 1.0f)) {
+                    t[0] = f * dot(e1, origin_cross_e0);
+                    ok[0] = true;
+                }
+            }
+        }
+        break;
+    }
+    }
+    offer_roots(v, s, n1_visible, t, ok);
+}
+
+// World.intersect + Group.intersect (src/world.zig:38-47, src/group.zig:55-87) over the
+// flattened node/shape arrays.  The node and shape loops are wave-uniform (records come in
+// through scalar loads); a lane whose ray failed a group's box is parked until the loop
+// leaves that group's subtree.  `lane_on` is false for padding lanes.
+template <class V>
+__device__ __forceinline__ void traverse(V& v, const Params& p, V4 o, V4 d, bool lane_on) {
+    uint32_t parked_until = lane_on ? 0u : kNone;  // node index at which this lane wakes up
+    for (uint32_t n = 0; n < p.n_nodes; ++n) {
+        const rtx_node& node = p.nodes[n];
+        bool active = n >= parked_until && !v.done();
+        if (active && node.has_bounds && !bounds_hit(node, o, d)) {
+            parked_until = node.skip;
+            active = false;
+        }
+        if (__ballot(active) == 0ull) continue;
+        const uint32_t first = node.first_shape;
+        const uint32_t last = first + node.n_shapes;
+        for (uint32_t s = first; s < last; ++s) {
+            if (active) intersect_shape(v, p.shapes[s], s, o, d);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------ shading
+
+// Shape.normalAt for the hit shape (per-lane record).
+__device__ __forceinline__ V4 normal_at(const rtx_shape& sh, V4 world_point) {
+    const float* inv = sh.inverse;
+    V4 object_normal;
+    switch (sh.type) {
+    case RTX_SPHERE: {  // src/sphere.zig:56-82
+        const V4 object_point = mul_mat(inv, world_point);
+        object_normal = sub(object_point, v4(0.0f, 0.0f, 0.0f, 1.0f));
+        break;
+    }
+    case RTX_PLANE:  // src/plane.zig:30-46
+        object_normal = v4(0.0f, 1.0f, 0.0f, 0.0f);
+        break;
+    case RTX_CUBE: {  // src/cube.zig:28-44 — w is NOT reset before normalising
+        const V4 object_point = mul_mat(inv, world_point);
+        const float x = fabsf(object_point.x), y = fabsf(object_point.y), z = fabsf(object_point.z);
+        const float maxc = fmaxf(x, fmaxf(y, z));
+        if (maxc == x) object_normal = v4(object_point.x, 0.0f, 0.0f, 0.0f);
+        else if (maxc == y) object_normal = v4(0.0f, object_point.y, 0.0f, 0.0f);
+        else object_normal = v4(0.0f, 0.0f, object_point.z, 0.0f);
+        return normalize(mul_mat_t(inv, object_normal));
+    }
+    case RTX_CYLINDER: {  // src/cylinder.zig:73-92
+        const V4 object_point = mul_mat(inv, world_point);
+        const float distance = object_point.x * object_point.x + object_point.z * object_point.z;
+        if (distance < 1.0f && object_point.y >= sh.maximum - kEpsilon) object_normal = v4(0.0f, 1.0f, 0.0f, 0.0f);
+        else if (distance < 1.0f && object_point.y <= sh.minimum + kEpsilon) object_normal = v4(0.0f, -1.0f, 0.0f, 0.0f);
+        else object_normal = v4(object_point.x, 0.0f, object_point.z, 0.0f);
+        break;
+    }
+    case RTX_CONE: {  // src/cone.zig:84-105
+        const V4 object_point = mul_mat(inv, world_point);
+        const float distance = object_point.x * object_point.x + object_point.z * object_point.z;
+        if (distance < sh.maximum * sh.maximum && object_point.y >= sh.maximum - kEpsilon) {
+            object_normal = v4(0.0f, 1.0f, 0.0f, 0.0f);
+        } else if (distance < sh.minimum * sh.minimum && object_point.y <= sh.minimum + kEpsilon) {
+            object_normal = v4(0.0f, -1.0f, 0.0f, 0.0f);
+        } else {
+            const float y = (object_point.y > 0.0f) ? -sqrtf(distance) : sqrtf(distance);
+            object_normal = v4(object_point.x, y, object_point.z, 0.0f);
+        }
+        break;
+    }
+    default:  // src/triangle.zig:52-61
+        object_normal = v4(sh.normal[0], sh.normal[1], sh.normal[2], sh.normal[3]);
+        break;
+    }
+    V4 world_normal = mul_mat_t(inv, object_normal);
+    world_normal.w = 0.0f;
+    return normalize(world_normal);
+}
+
+// @mod(x, 2) == 0 under floored modulo  <=>  fmodf(x, 2) is +-0.
+__device__ __forceinline__ bool mod2_is_zero(float x) { return fmodf(x, 2.0f) == 0.0f; }
+
+struct Color {
+    float r, g, b;
+};
+
+// Pattern.atShape (src/pattern.zig:23-51)
+__device__ __forceinline__ Color pattern_at_shape(const rtx_pattern& pat, const rtx_shape& sh, V4 world_point) {
+    const V4 object_point = mul_mat(sh.inverse, world_point);
+    const V4 pt = mul_mat(pat.inverse, object_point);
+    const Color a{pat.a[0], pat.a[1], pat.a[2]}, b{pat.b[0], pat.b[1], pat.b[2]};
+    switch (pat.color_map) {
+    case RT_PATTERN_STRIPE:
+        return mod2_is_zero(floorf(pt.x)) ? a : b;
+    case RT_PATTERN_GRADIENT: {
+        const float fraction = pt.x - floorf(pt.x);
+        return Color{a.r + (b.r - a.r) * fraction, a.g + (b.g - a.g) * fraction, a.b + (b.b - a.b) * fraction};
+    }
+    case RT_PATTERN_RING:
+        return mod2_is_zero(floorf(sqrtf(pt.x * pt.x + pt.z * pt.z))) ? a : b;
+    default:
+        return mod2_is_zero(floorf(pt.x) + floorf(pt.y) + floorf(pt.z)) ? a : b;
+    }
+}
+
+// Material.lighting (src/material.zig:40-102)
+__device__ __forceinline__ Color lighting(const Params& p, const rtx_material& m, const rtx_shape& sh, V4 point, V4 eye,
+                                          V4 normal, bool in_shadow) {
+    Color color;
+    if (m.pattern >= 0) color = pattern_at_shape(p.patterns[m.pattern], sh, point);
+    else color = Color{m.color[0], m.color[1], m.color[2]};
+
+    const Color li{p.light_intensity[0], p.light_intensity[1], p.light_intensity[2]};
+    const Color effective{color.r * li.r, color.g * li.g, color.b * li.b};
+    const V4 lp = v4(p.light_position[0], p.light_position[1], p.light_position[2], p.light_position[3]);
+    const V4 light_direction = normalize(sub(lp, point));
+    const Color ambient{effective.r * m.ambient, effective.g * m.ambient, effective.b * m.ambient};
+    if (in_shadow) return ambient;
+
+    Color diffuse{0.0f, 0.0f, 0.0f}, specular{0.0f, 0.0f, 0.0f};
+    const float cos_light_normal = dot(light_direction, normal);
+    if (!(cos_light_normal < 0.0f)) {
+        diffuse = Color{effective.r * m.diffuse * cos_light_normal, effective.g * m.diffuse * cos_light_normal,
+                        effective.b * m.diffuse * cos_light_normal};
+        const V4 refl = reflect(neg(light_direction), normal);
+        const float cos_reflect_eye = dot(refl, eye);
+        if (!(cos_reflect_eye <= 0.0f)) {
+            const float factor = rt::zmath::pow_f32(cos_reflect_eye, m.shininess);
+            specular = Color{li.r * m.specular * factor, li.g * m.specular * factor, li.b * m.specular * factor};
+        }
+    }
+    return Color{ambient.r + diffuse.r + specular.r, ambient.g + diffuse.g + specular.g, ambient.b + diffuse.b + specular.b};
+}
+
+// schlick (src/intersection.zig:161-180)
+__device__ __forceinline__ float schlick(float n1, float n2, V4 eye, V4 normal) {
+    float r0 = (n1 - n2) / (n1 + n2);
+    r0 *= r0;
+    float cosv = dot(eye, normal);
+    if (n1 > n2) {
+        const float n = n1 / n2;
+        const float sin2_t = n * n * (1.0f - cosv * cosv);
+        if (sin2_t > 1.0f) return 1.0f;
+        cosv = sqrtf(1.0f - sin2_t);
+    }
+    return r0 + (1.0f - r0) * rt::zmath::pow_f32(1.0f - cosv, 5.0f);
+}
+
+// shadeHitInternal's final expression (src/world.zig:71-78)
+__device__ __forceinline__ Color combine(Color surface, Color reflected, Color refracted, bool use_schlick, float reflectance) {
+    if (use_schlick) {
+        const float k = 1.0f - reflectance;
+        return Color{surface.r + reflected.r * reflectance + refracted.r * k,
+                     surface.g + reflected.g * reflectance + refracted.g * k,
+                     surface.b + reflected.b * reflectance + refracted.b * k};
+    }
+    return Color{surface.r + reflected.r + refracted.r, surface.g + reflected.g + refracted.g,
+                 surface.b + reflected.b + refracted.b};
+}
+
+// ------------------------------------------------------------- queues and delivery
+
+// One slot index per active lane, one atomic per wave.
+__device__ __forceinline__ uint32_t wave_alloc(uint32_t* counter, bool want) {
+    const unsigned long long mask = __ballot(want);
+    if (mask == 0ull) return 0;
+    const uint32_t total = __popcll(mask);
+    const uint32_t lane = __lane_id();
+    const uint32_t rank = __popcll(mask & ((1ull << lane) - 1ull));
+    uint32_t base = 0;
+    const uint32_t leader = __ffsll(static_cast<long long>(mask)) - 1;
+    if (lane == leader) base = atomicAdd(counter, total);
+    base = __shfl(base, leader);
+    return base + rank;
+}
+
+// Hand a finished colour to whoever asked for it: the canvas at the root
+// (canvas.writePixel, src/canvas.zig:34-36), otherwise the parent's reflected / refracted
+// slot, scaled by the parent's reflective / transparency (src/world.zig:142,185).
+__device__ __forceinline__ void deliver(const Params& p, bool root, uint32_t link, float weight, Color c) {
+    if (root) {
+        float* px = p.canvas + 3ull * (link & kLinkIndexMask);
+        px[0] = c.r;
+        px[1] = c.g;
+        px[2] = c.b;
+    } else {
+        const uint32_t parent = link & kLinkIndexMask;
+        float4* slot = (link & kLinkSlotBit) ? &p.node_c[parent] : &p.node_b[parent];
+        float* f = reinterpret_cast<float*>(slot);
+        f[0] = c.r * weight;
+        f[1] = c.g * weight;
+        f[2] = c.b * weight;
+    }
+}
+
+// ------------------------------------------------------------------------ kernels
+
+// One ray-tree level.  GEN: level-0 rays come from the camera (rayForPixel,
+// src/camera.zig:70-82) instead of the queue.  TRACK: keep the n1 predecessor.
+template <bool GEN, bool TRACK>
+__global__ __launch_bounds__(256) void k_trace_shade(const Params p, const uint32_t level) {
+    const bool root = level == 0;
+    const uint32_t remaining = p.depth - level;  // `remaining` of colorAtInternal (src/world.zig:85)
+    uint32_t count;
+    if (GEN) count = p.tiles_x * ((p.n_rows + 7u) / 8u) * 64u;
+    else count = root ? p.root_count : p.counters->queue_count[level];
+    const uint32_t qi = level & 1u, qo = qi ^ 1u;
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+
+    uint32_t local_hits = 0;
+    for (uint32_t base = wave * 64u; base < count; base += n_waves * 64u) {
+        const uint32_t i = base + lane;
+        bool on = i < count;
+        V4 o, d;
+        uint32_t link = 0;
+        float weight = 1.0f;
+        if (GEN) {
+            // 8x8 pixel tile per wave over this batch's local rows.
+            const uint32_t tile = i >> 6;
+            const uint32_t tx = tile % p.tiles_x, ty = tile / p.tiles_x;
+            const uint32_t px = tx * 8u + (lane & 7u);
+            const uint32_t lrow = p.row0 + ty * 8u + (lane >> 3);  // local row among the rows this call renders
+            on = on && px < p.width && lrow < p.row0 + p.n_rows;
+            uint32_t py = lrow;
+            if (p.strip_count > 1u) {
+                const uint32_t ls = lrow / p.strip_rows;
+                py = (ls * p.strip_count + p.strip_index) * p.strip_rows + (lrow - ls * p.strip_rows);
+            }
+            const float x_offset = (static_cast<float>(px) + 0.5f) * p.pixel_size;
+            const float y_offset = (static_cast<float>(py) + 0.5f) * p.pixel_size;
+            const float world_x = p.half_width - x_offset;
+            const float world_y = p.half_height - y_offset;
+            const V4 pixel = mul_mat(p.cam_inv, v4(world_x, world_y, -1.0f, 1.0f));
+            o = mul_mat(p.cam_inv, v4(0.0f, 0.0f, 0.0f, 1.0f));
+            d = normalize(sub(pixel, o));
+            link = (p.compact_rows ? lrow : py) * p.width + px;
+        } else if (on) {
+            const float4 qo4 = p.q_org[qi][i];
+            const float4 qd4 = p.q_dir[qi][i];
+            const uint2 ql = p.q_link[qi][i];
+            o = v4(qo4.x, qo4.y, qo4.z, qo4.w);
+            d = v4(qd4.x, qd4.y, qd4.z, qd4.w);
+            link = ql.x;
+            weight = __uint_as_float(ql.y);
+        } else {
+            o = v4(0.0f, 0.0f, 0.0f, 1.0f);
+            d = v4(0.0f, 0.0f, 1.0f, 0.0f);
+        }
+
+        // colorAtInternal: world.intersect + hit (src/world.zig:85-95)
+        ClosestVisitor<TRACK> cv;
+        cv.init();
+        traverse(cv, p, o, d, on);
+        const bool is_hit = on && cv.c.idx != kNone;
+
+        // prepareComputations (src/intersection.zig:43-90) and the shadow ray
+        // (src/world.zig:55,97-106), per lane.
+        V4 point = o, normal = d, over_point = o, shadow_dir = d;
+        float n1 = 1.0f, n2 = 1.0f, shadow_distance = 0.0f;
+        if (is_hit) {
+            ++local_hits;
+            const rtx_shape& sh = p.shapes[cv.c.idx];
+            point = add(o, muls(d, cv.c.t));  // ray.position, src/ray.zig:9-11
+            normal = normal_at(sh, point);
+            if (dot(normal, neg(d)) < 0.0f) normal = neg(normal);
+            // n1 / n2 (src/intersection.zig:92-159, see Closest above)
+            if (TRACK && cv.c.pred_idx != kNone) n1 = p.materials[p.shapes[cv.c.pred_idx].material].refractive_index;
+            n2 = p.materials[sh.material].refractive_index;
+            over_point = add(point, muls(normal, p.over_eps));
+            const V4 lp = v4(p.light_position[0], p.light_position[1], p.light_position[2], p.light_position[3]);
+            const V4 to_light = sub(lp, over_point);
+            shadow_distance = magnitude(to_light);
+            shadow_dir = normalize(to_light);
+        }
+
+        // isShadowed (src/world.zig:97-120).  The traversal loop is wave-uniform, so it runs
+        // outside the divergent branch; lanes without a hit are parked.
+        ShadowVisitor sv;
+        sv.distance = shadow_distance;
+        sv.found = false;
+        traverse(sv, p, over_point, shadow_dir, is_hit);
+
+        bool spawn_reflect = false, spawn_refract = false, use_schlick = false;
+        float reflectance = 0.0f, reflective = 0.0f, transparency = 0.0f;
+        Color surface{0.0f, 0.0f, 0.0f};
+        V4 reflectv = d, under_point = o, refract_dir = d;
+        if (is_hit) {
+            const rtx_shape& sh = p.shapes[cv.c.idx];
+            const rtx_material& m = p.materials[sh.material];
+            const V4 eye = neg(d);
+            reflectv = reflect(d, normal);
+            reflective = m.reflective;
+            transparency = m.transparency;
+            // shadeHitInternal (src/world.zig:54-79): Phong is evaluated at over_point.
+            surface = lighting(p, m, sh, over_point, eye, normal, sv.found);
+            // reflectedColorInternal (src/world.zig:126-143)
+            spawn_reflect = remaining != 0u && m.reflective != 0.0f;
+            // refractedColorInternal (src/world.zig:149-186)
+            if (remaining != 0u && m.transparency != 0.0f) {
+                const float n_ratio = n1 / n2;
+                const float cos_i = dot(eye, normal);
+                const float sin2_t = (n_ratio * n_ratio) * (1.0f - cos_i * cos_i);
+                if (!(sin2_t > 1.0f)) {
+                    const float cos_t = sqrtf(1.0f - sin2_t);
+                    spawn_refract = true;
+                    under_point = sub(point, muls(normal, p.over_eps));
+                    refract_dir = sub(muls(normal, n_ratio * cos_i - cos_t), muls(eye, n_ratio));
+                }
+            }
+            if (m.reflective > 0.0f && m.transparency > 0.0f) {
+                use_schlick = true;
+                reflectance = schlick(n1, n2, eye, normal);
+            }
+        }
+
+        // Leaves finish here; interior nodes park their surface colour for k_combine.
+        const bool interior = spawn_reflect || spawn_refract;
+        if (on && !interior) {
+            // A miss is black (src/world.zig:94); a hit without children adds two blacks.
+            const Color black{0.0f, 0.0f, 0.0f};
+            const Color out = is_hit ? combine(surface, black, black, use_schlick, reflectance) : black;
+            deliver(p, root, link, weight, out);
+        }
+        const uint32_t node_local = wave_alloc(&p.counters->node_count[level], interior);
+        uint32_t node = 0;
+        if (interior) {
+            node = p.node_off[level] + node_local;
+            p.node_a[node] = make_float4(surface.r, surface.g, surface.b, reflectance);
+            p.node_b[node] = make_float4(0.0f, 0.0f, 0.0f, weight);
+            uint32_t bits = (link & (kLinkIndexMask | kLinkSlotBit)) | (use_schlick ? kLinkSchlickBit : 0u);
+            p.node_c[node] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(bits));
+        }
+        const uint32_t r_slot = wave_alloc(&p.counters->queue_count[level + 1], spawn_reflect);
+        if (spawn_reflect) {
+            p.q_org[qo][r_slot] = make_float4(over_point.x, over_point.y, over_point.z, over_point.w);
+            p.q_dir[qo][r_slot] = make_float4(reflectv.x, reflectv.y, reflectv.z, reflectv.w);
+            p.q_link[qo][r_slot] = make_uint2(node, __float_as_uint(reflective));
+        }
+        const uint32_t t_slot = wave_alloc(&p.counters->queue_count[level + 1], spawn_refract);
+        if (spawn_refract) {
+            p.q_org[qo][t_slot] = make_float4(under_point.x, under_point.y, under_point.z, under_point.w);
+            p.q_dir[qo][t_slot] = make_float4(refract_dir.x, refract_dir.y, refract_dir.z, refract_dir.w);
+            p.q_link[qo][t_slot] = make_uint2(node | kLinkSlotBit, __float_as_uint(transparency));
+        }
+    }
+    // one atomic per wave for the hit (= shadow ray) count
+    for (int off = 32; off > 0; off >>= 1) local_hits += __shfl_down(local_hits, off);
+    if (lane == 0 && local_hits) atomicAdd(&p.counters->hits[level], local_hits);
+}
+
+// Interior nodes of one level, after every deeper level has delivered into their slots.
+__global__ __launch_bounds__(256) void k_combine(const Params p, const uint32_t level) {
+    const uint32_t count = p.counters->node_count[level];
+    const bool root = level == 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+        const uint32_t node = p.node_off[level] + i;
+        const float4 a = p.node_a[node], b = p.node_b[node], c = p.node_c[node];
+        const uint32_t bits = __float_as_uint(c.w);
+        const Color out = combine(Color{a.x, a.y, a.z}, Color{b.x, b.y, b.z}, Color{c.x, c.y, c.z},
+                                  (bits & kLinkSchlickBit) != 0u, a.w);
+        deliver(p, root, bits, b.w, out);
+    }
+}
+
+// Fold this batch's counters into the running totals and clear them for the next batch.
+__global__ void k_accumulate(Counters* c, Totals* t, uint32_t level0_rays, uint32_t depth) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    t->level_rays[0] += level0_rays;
+    for (uint32_t l = 1; l <= depth; ++l) t->level_rays[l] += c->queue_count[l];
+    for (uint32_t l = 0; l <= depth; ++l) {
+        t->hits += c->hits[l];
+        t->nodes += c->node_count[l];
+    }
+    for (int l = 0; l <= kLevels; ++l) c->queue_count[l] = 0;
+    for (int l = 0; l < kLevels; ++l) {
+        c->node_count[l] = 0;
+        c->hits[l] = 0;
+    }
+}
+
+// canvas.zig:45-47: round(clamp(c * 255, 0, 255)), round half away from zero.
+__global__ void k_quantise(const float* rgb, uint8_t* out, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float v = rgb[i] * 255.0f;
+        v = fmaxf(0.0f, fminf(v, 255.0f));
+        out[i] = static_cast<uint8_t>(roundf(v));
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------- host side
+
+struct rtx_scene {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    rtx_shape* d_shapes = nullptr;
+    rtx_node* d_nodes = nullptr;
+    rtx_material* d_materials = nullptr;
+    rtx_pattern* d_patterns = nullptr;
+    uint32_t n_shapes = 0, n_nodes = 0, n_materials = 0, n_patterns = 0;
+    bool track_n1 = false;
+    float light_position[4];
+    float light_intensity[3];
+
+    // work buffers, sized for `cap_pixels` pixels per batch at depth kMaxDepth
+    uint32_t cap_pixels = 0;
+    float4* q_org[2] = {nullptr, nullptr};
+    float4* q_dir[2] = {nullptr, nullptr};
+    uint2* q_link[2] = {nullptr, nullptr};
+    float4* node_a = nullptr;
+    float4* node_b = nullptr;
+    float4* node_c = nullptr;
+    Counters* d_counters = nullptr;
+    Totals* d_totals = nullptr;
+    float* d_canvas = nullptr;  // staging canvas for the host-output entry points
+    size_t canvas_floats = 0;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    int num_cus = 256;
+};
+
+namespace {
+
+void free_work(rtx_scene* s) {
+    for (int i = 0; i < 2; ++i) {
+        if (s->q_org[i]) (void)hipFree(s->q_org[i]);
+        if (s->q_dir[i]) (void)hipFree(s->q_dir[i]);
+        if (s->q_link[i]) (void)hipFree(s->q_link[i]);
+        s->q_org[i] = s->q_dir[i] = nullptr;
+        s->q_link[i] = nullptr;
+    }
+    if (s->node_a) (void)hipFree(s->node_a);
+    if (s->node_b) (void)hipFree(s->node_b);
+    if (s->node_c) (void)hipFree(s->node_c);
+    s->node_a = s->node_b = s->node_c = nullptr;
+    s->cap_pixels = 0;
+}
+
+// Worst-case sizing: a hit spawns at most two children, so level d holds at most
+// 2^d * pixels rays and as many interior nodes; no overflow path is needed.
+int ensure_work(rtx_scene* s, uint32_t pixels) {
+    if (pixels <= s->cap_pixels) return RTX_OK;
+    free_work(s);
+    const size_t q_cap = (size_t)pixels << kMaxDepth;  // largest level
+    size_t node_cap = 0;
+    for (int l = 0; l < kMaxDepth; ++l) node_cap += (size_t)pixels << l;
+    for (int i = 0; i < 2; ++i) {
+        HIP_TRY(hipMalloc(&s->q_org[i], q_cap * sizeof(float4)));
+        HIP_TRY(hipMalloc(&s->q_dir[i], q_cap * sizeof(float4)));
+        HIP_TRY(hipMalloc(&s->q_link[i], q_cap * sizeof(uint2)));
+    }
+    HIP_TRY(hipMalloc(&s->node_a, node_cap * sizeof(float4)));
+    HIP_TRY(hipMalloc(&s->node_b, node_cap * sizeof(float4)));
+    HIP_TRY(hipMalloc(&s->node_c, node_cap * sizeof(float4)));
+    s->cap_pixels = pixels;
+    return RTX_OK;
+}
+
+int ensure_canvas(rtx_scene* s, size_t floats) {
+    if (floats <= s->canvas_floats) return RTX_OK;
+    if (s->d_canvas) (void)hipFree(s->d_canvas);
+    s->d_canvas = nullptr;
+    s->canvas_floats = 0;
+    HIP_TRY(hipMalloc(&s->d_canvas, floats * sizeof(float)));
+    s->canvas_floats = floats;
+    return RTX_OK;
+}
+
+struct RowPlan {
+    uint32_t rows_total;   // rows of the frame that are rendered at all (rows quirk applied)
+    uint32_t rows_local;   // rows this call renders
+    uint32_t strip_rows, strip_count, strip_index;
+};
+
+RowPlan plan_rows(const rtx_camera* cam, const rtx_opts* o) {
+    RowPlan r;
+    const uint32_t h = cam->vertical_size;
+    r.rows_total = (o && o->rows_quirk) ? 8u * (h / 8u) : h;  // src/camera.zig:87-88
+    r.strip_count = (o && o->strip_count > 1) ? o->strip_count : 1;
+    r.strip_rows = (o && o->strip_rows) ? o->strip_rows : 8;
+    r.strip_index = (o && r.strip_count > 1) ? o->strip_index : 0;
+    if (r.strip_count == 1) {
+        r.rows_local = r.rows_total;
+    } else {
+        // strips s = strip_index, strip_index + strip_count, ... of strip_rows rows each
+        uint32_t rows = 0;
+        for (uint32_t s = r.strip_index;; s += r.strip_count) {
+            const uint64_t y0 = (uint64_t)s * r.strip_rows;
+            if (y0 >= r.rows_total) break;
+            const uint64_t y1 = y0 + r.strip_rows;
+            rows += (uint32_t)((y1 > r.rows_total ? r.rows_total : y1) - y0);
+        }
+        r.rows_local = rows;
+    }
+    return r;
+}
+
+template <bool GEN>
+void launch_trace(const rtx_scene* s, const Params& p, uint32_t level, uint32_t blocks, hipStream_t st) {
+    if (s->track_n1) hipLaunchKernelGGL((k_trace_shade<GEN, true>), dim3(blocks), dim3(256), 0, st, p, level);
+    else hipLaunchKernelGGL((k_trace_shade<GEN, false>), dim3(blocks), dim3(256), 0, st, p, level);
+}
+
+int validate_desc(const rtx_scene_desc* d) {
+    if (!d) return fail(RTX_E_INVALID, "scene descriptor is NULL");
+    if (d->n_nodes == 0 || !d->nodes) return fail(RTX_E_INVALID, "scene needs at least the world node");
+    if (d->n_shapes && !d->shapes) return fail(RTX_E_INVALID, "shapes is NULL");
+    if (d->n_materials == 0 || !d->materials) return fail(RTX_E_INVALID, "scene needs at least one material");
+    if (d->n_patterns && !d->patterns) return fail(RTX_E_INVALID, "patterns is NULL");
+    if (d->n_shapes > kLinkIndexMask) return fail(RTX_E_INVALID, "too many shapes");
+    for (uint32_t i = 0; i < d->n_shapes; ++i) {
+        const rtx_shape& s = d->shapes[i];
+        if (s.type > RTX_TRIANGLE) return fail(RTX_E_INVALID, "shape %u: bad type %u", i, s.type);
+        if (s.material >= d->n_materials) return fail(RTX_E_INVALID, "shape %u: material %u out of range", i, s.material);
+    }
+    for (uint32_t i = 0; i < d->n_materials; ++i)
+        if (d->materials[i].pattern >= (int32_t)d->n_patterns)
+            return fail(RTX_E_INVALID, "material %u: pattern %d out of range", i, d->materials[i].pattern);
+    for (uint32_t i = 0; i < d->n_patterns; ++i)
+        if (d->patterns[i].color_map > RT_PATTERN_CHECKER) return fail(RTX_E_INVALID, "pattern %u: bad color_map", i);
+    uint32_t next_shape = 0;
+    for (uint32_t i = 0; i < d->n_nodes; ++i) {
+        const rtx_node& n = d->nodes[i];
+        // Nodes own consecutive shape ranges in insertion order, and skip must move forward:
+        // the traversal loop relies on both.
+        if (n.first_shape != next_shape) return fail(RTX_E_INVALID, "node %u: shapes are not in insertion order", i);
+        if ((uint64_t)n.first_shape + n.n_shapes > d->n_shapes) return fail(RTX_E_INVALID, "node %u: shape range out of bounds", i);
+        if (n.skip <= i || n.skip > d->n_nodes) return fail(RTX_E_INVALID, "node %u: skip %u does not move forward", i, n.skip);
+        next_shape += n.n_shapes;
+    }
+    if (next_shape != d->n_shapes) return fail(RTX_E_INVALID, "nodes cover %u of %u shapes", next_shape, d->n_shapes);
+    return RTX_OK;
+}
+
+int check_camera(const rtx_camera* cam) {
+    if (!cam) return fail(RTX_E_INVALID, "camera is NULL");
+    if (cam->horizontal_size == 0 || cam->vertical_size == 0) return fail(RTX_E_INVALID, "empty canvas");
+    if ((uint64_t)cam->horizontal_size * cam->vertical_size > kLinkIndexMask) return fail(RTX_E_INVALID, "canvas too large");
+    return RTX_OK;
+}
+
+void fill_scene_params(const rtx_scene* s, Params& p, uint32_t depth) {
+    std::memset(&p, 0, sizeof p);
+    p.shapes = s->d_shapes;
+    p.nodes = s->d_nodes;
+    p.materials = s->d_materials;
+    p.patterns = s->d_patterns;
+    p.n_nodes = s->n_nodes;
+    p.n_shapes = s->n_shapes;
+    p.track_n1 = s->track_n1 ? 1u : 0u;
+    p.depth = depth;
+    std::memcpy(p.light_position, s->light_position, sizeof p.light_position);
+    std::memcpy(p.light_intensity, s->light_intensity, sizeof p.light_intensity);
+    p.over_eps = kEpsilon * 100.0f;  // f32 product, one ulp below 0.001f (src/world.zig:55)
+    for (int i = 0; i < 2; ++i) {
+        p.q_org[i] = s->q_org[i];
+        p.q_dir[i] = s->q_dir[i];
+        p.q_link[i] = s->q_link[i];
+    }
+    p.node_a = s->node_a;
+    p.node_b = s->node_b;
+    p.node_c = s->node_c;
+    p.counters = s->d_counters;
+}
+
+struct ProfileEvents {
+    std::vector<hipEvent_t> ev;
+    std::vector<int> kind;  // 0 trace_shade, 1 combine
+    ~ProfileEvents() {
+        for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+    }
+};
+
+// Run the levels for one batch whose level-0 rays are either generated (GEN) or already in
+// queue 0 (rtx_color_at).
+template <bool GEN>
+int run_levels(rtx_scene* s, Params& p, uint32_t pixels, uint32_t level0_items, hipStream_t st, ProfileEvents* prof) {
+    uint32_t off = 0;
+    for (int l = 0; l < kLevels; ++l) {
+        p.node_off[l] = off;
+        if (l < kMaxDepth) off += pixels << l;
+    }
+    const uint32_t max_blocks = (uint32_t)s->num_cus * 8u;
+    auto mark = [&](int kind) {
+        if (!prof) return;
+        hipEvent_t e;
+        (void)hipEventCreate(&e);
+        (void)hipEventRecord(e, st);
+        prof->ev.push_back(e);
+        prof->kind.push_back(kind);
+    };
+    for (uint32_t level = 0; level <= p.depth; ++level) {
+        // Level 0 knows its size; deeper levels read theirs on the device and grid-stride.
+        uint64_t items = level == 0 ? level0_items : ((uint64_t)pixels << level);
+        uint32_t blocks = (uint32_t)((items + 255) / 256);
+        if (blocks > max_blocks) blocks = max_blocks;
+        if (blocks == 0) blocks = 1;
+        mark(0);
+        if (level == 0) launch_trace<GEN>(s, p, level, blocks, st);
+        else launch_trace<false>(s, p, level, blocks, st);
+        mark(-1);
+    }
+    for (int level = (int)p.depth - 1; level >= 0; --level) {
+        uint64_t items = (uint64_t)pixels << level;
+        uint32_t blocks = (uint32_t)((items + 255) / 256);
+        if (blocks > max_blocks) blocks = max_blocks;
+        mark(1);
+        hipLaunchKernelGGL(k_combine, dim3(blocks), dim3(256), 0, st, p, (uint32_t)level);
+        mark(-1);
+    }
+    hipLaunchKernelGGL(k_accumulate, dim3(1), dim3(64), 0, st, s->d_counters, s->d_totals, level0_items ? pixels : 0u, p.depth);
+    HIP_TRY(hipGetLastError());
+    return RTX_OK;
+}
+
+int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_opts* opts, float* d_rgb, uint8_t* d_rgb8,
+                hipStream_t st, rtx_stats* stats) {
+    int rc = check_camera(cam);
+    if (rc) return rc;
+    uint32_t depth = (opts && opts->depth) ? opts->depth : kMaxDepth;
+    if (depth > kMaxDepth) return fail(RTX_E_INVALID, "depth %u exceeds ray_depth_limit %d", depth, kMaxDepth);
+    if (opts && opts->strip_count > 1 && opts->strip_index >= opts->strip_count)
+        return fail(RTX_E_INVALID, "strip_index %u >= strip_count %u", opts->strip_index, opts->strip_count);
+    HIP_TRY(hipSetDevice(s->device));
+
+    const RowPlan plan = plan_rows(cam, opts);
+    const uint32_t W = cam->horizontal_size, H = cam->vertical_size;
+    const bool compact = opts && opts->compact_rows;
+    const bool profile = opts && opts->profile;
+    const size_t out_rows = compact ? plan.rows_local : H;
+
+    // Batch: whole 8-row bands, at most batch_pixels pixels.
+    uint32_t batch_pixels = (opts && opts->batch_pixels) ? opts->batch_pixels : (1u << 20);
+    if (batch_pixels > (1u << 22)) batch_pixels = 1u << 22;  // keeps (pixels << depth) inside 30 bits
+    uint32_t rows_per_batch = (batch_pixels / W) & ~7u;
+    if (rows_per_batch < 8) rows_per_batch = 8;
+    if (rows_per_batch > ((plan.rows_local + 7u) & ~7u)) rows_per_batch = (plan.rows_local + 7u) & ~7u;
+    if (rows_per_batch == 0) rows_per_batch = 8;
+    const uint32_t tiles_x = (W + 7u) / 8u;
+    const uint32_t cap = tiles_x * 8u * rows_per_batch;  // pixels incl. tile padding
+    rc = ensure_work(s, cap);
+    if (rc) return rc;
+
+    Params p;
+    fill_scene_params(s, p, depth);
+    std::memcpy(p.cam_inv, cam->inverse_transform, sizeof p.cam_inv);
+    p.half_width = cam->half_width;
+    p.half_height = cam->half_height;
+    p.pixel_size = cam->pixel_size;
+    p.width = W;
+    p.tiles_x = tiles_x;
+    p.strip_rows = plan.strip_rows;
+    p.strip_count = plan.strip_count;
+    p.strip_index = plan.strip_index;
+    p.compact_rows = compact ? 1u : 0u;
+    p.canvas = d_rgb;
+
+    HIP_TRY(hipEventRecord(s->ev_begin, st));
+    // Canvas starts black (canvas.zig:23-25); rows never rendered stay black.
+    HIP_TRY(hipMemsetAsync(d_rgb, 0, out_rows * W * 3 * sizeof(float), st));
+    HIP_TRY(hipMemsetAsync(s->d_counters, 0, sizeof(Counters), st));
+    HIP_TRY(hipMemsetAsync(s->d_totals, 0, sizeof(Totals), st));
+
+    ProfileEvents prof;
+    for (uint32_t row0 = 0; row0 < plan.rows_local; row0 += rows_per_batch) {
+        const uint32_t n_rows = (plan.rows_local - row0 < rows_per_batch) ? plan.rows_local - row0 : rows_per_batch;
+        p.row0 = row0;
+        p.n_rows = n_rows;
+        const uint32_t items = tiles_x * ((n_rows + 7u) / 8u) * 64u;
+        rc = run_levels<true>(s, p, cap, items, st, profile ? &prof : nullptr);
+        if (rc) return rc;
+    }
+    if (d_rgb8) {
+        const size_t n = out_rows * W * 3;
+        hipLaunchKernelGGL(k_quantise, dim3(2048), dim3(256), 0, st, d_rgb, d_rgb8, n);
+    }
+    HIP_TRY(hipEventRecord(s->ev_end, st));
+    HIP_TRY(hipGetLastError());
+
+    if (stats) {
+        std::memset(stats, 0, sizeof *stats);
+        Totals t;
+        HIP_TRY(hipMemcpyAsync(&t, s->d_totals, sizeof t, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        // k_accumulate counts tile padding at level 0; the rays that exist are the pixels.
+        stats->rays_primary = (uint64_t)plan.rows_local * W;
+        stats->level_rays[0] = stats->rays_primary;
+        for (uint32_t l = 1; l <= depth; ++l) {
+            stats->level_rays[l] = t.level_rays[l];
+            stats->rays_secondary += t.level_rays[l];
+        }
+        stats->rays_shadow = t.hits;
+        stats->nodes = t.nodes;
+        stats->rows_rendered = plan.rows_local;
+        HIP_TRY(hipEventElapsedTime(&stats->ms_total, s->ev_begin, s->ev_end));
+        if (profile) {
+            for (size_t i = 0; i + 1 < prof.ev.size(); i += 2) {
+                float ms = 0.0f;
+                HIP_TRY(hipEventElapsedTime(&ms, prof.ev[i], prof.ev[i + 1]));
+                if (prof.kind[i] == 0) {
+                    stats->ms_trace_shade += ms;
+                    stats->launches_trace_shade++;
+                } else {
+                    stats->ms_combine += ms;
+                    stats->launches_combine++;
+                }
+            }
+        }
+    }
+    return RTX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rtx_last_error(void) { return g_err; }
+
+int rtx_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return fail(RTX_E_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    return n;
+}
+
+int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out) {
+    if (!out) return fail(RTX_E_INVALID, "out is NULL");
+    *out = nullptr;
+    int rc = validate_desc(desc);
+    if (rc) return rc;
+    int n = rtx_device_count();
+    if (n <= 0) return fail(RTX_E_NO_DEVICE, "no HIP device available (this library has no CPU path)");
+    if (device < 0 || device >= n) return fail(RTX_E_INVALID, "device %d out of range (0..%d)", device, n - 1);
+    HIP_TRY(hipSetDevice(device));
+
+    rtx_scene* s = new (std::nothrow) rtx_scene();
+    if (!s) return fail(RTX_E_NOMEM, "out of host memory");
+    s->device = device;
+    auto bail = [&](int code) {
+        rtx_scene_destroy(s);
+        return code;
+    };
+#define HIP_TRY_S(expr)                                                                                  \
+    do {                                                                                                 \
+        hipError_t e_ = (expr);                                                                          \
+        if (e_ != hipSuccess) return bail(fail(RTX_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)));      \
+    } while (0)
+    hipDeviceProp_t prop;
+    HIP_TRY_S(hipGetDeviceProperties(&prop, device));
+    s->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    HIP_TRY_S(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    HIP_TRY_S(hipEventCreate(&s->ev_begin));
+    HIP_TRY_S(hipEventCreate(&s->ev_end));
+
+    s->n_shapes = desc->n_shapes;
+    s->n_nodes = desc->n_nodes;
+    s->n_materials = desc->n_materials;
+    s->n_patterns = desc->n_patterns;
+    std::memcpy(s->light_position, desc->light_position, sizeof s->light_position);
+    std::memcpy(s->light_intensity, desc->light_intensity, sizeof s->light_intensity);
+    for (uint32_t i = 0; i < desc->n_shapes; ++i)
+        if (desc->materials[desc->shapes[i].material].transparency != 0.0f) s->track_n1 = true;
+
+    auto upload = [&](void** dst, const void* src, size_t bytes) -> hipError_t {
+        hipError_t e = hipMalloc(dst, bytes ? bytes : 16);
+        if (e != hipSuccess) return e;
+        if (bytes) e = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+        return e;
+    };
+    HIP_TRY_S(upload((void**)&s->d_shapes, desc->shapes, sizeof(rtx_shape) * desc->n_shapes));
+    HIP_TRY_S(upload((void**)&s->d_nodes, desc->nodes, sizeof(rtx_node) * desc->n_nodes));
+    HIP_TRY_S(upload((void**)&s->d_materials, desc->materials, sizeof(rtx_material) * desc->n_materials));
+    HIP_TRY_S(upload((void**)&s->d_patterns, desc->patterns, sizeof(rtx_pattern) * desc->n_patterns));
+    HIP_TRY_S(hipMalloc(&s->d_counters, sizeof(Counters)));
+    HIP_TRY_S(hipMalloc(&s->d_totals, sizeof(Totals)));
+#undef HIP_TRY_S
+    *out = s;
+    return RTX_OK;
+}
+
+void rtx_scene_destroy(rtx_scene* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    free_work(s);
+    if (s->d_canvas) (void)hipFree(s->d_canvas);
+    if (s->d_shapes) (void)hipFree(s->d_shapes);
+    if (s->d_nodes) (void)hipFree(s->d_nodes);
+    if (s->d_materials) (void)hipFree(s->d_materials);
+    if (s->d_patterns) (void)hipFree(s->d_patterns);
+    if (s->d_counters) (void)hipFree(s->d_counters);
+    if (s->d_totals) (void)hipFree(s->d_totals);
+    if (s->ev_begin) (void)hipEventDestroy(s->ev_begin);
+    if (s->ev_end) (void)hipEventDestroy(s->ev_end);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+}
+
+int rtx_rows_for(const rtx_camera* cam, const rtx_opts* opts, uint32_t* n_rows) {
+    int rc = check_camera(cam);
+    if (rc) return rc;
+    if (!n_rows) return fail(RTX_E_INVALID, "n_rows is NULL");
+    if (opts && opts->strip_count > 1 && opts->strip_index >= opts->strip_count)
+        return fail(RTX_E_INVALID, "strip_index %u >= strip_count %u", opts->strip_index, opts->strip_count);
+    *n_rows = plan_rows(cam, opts).rows_local;
+    return RTX_OK;
+}
+
+int rtx_render_device(rtx_scene* s, const rtx_camera* cam, const rtx_opts* opts, void* d_rgb_out, void* d_rgb8_out,
+                      void* stream, rtx_stats* stats) {
+    if (!s) return fail(RTX_E_INVALID, "scene is NULL");
+    if (!d_rgb_out) return fail(RTX_E_INVALID, "d_rgb_out is NULL");
+    hipStream_t st = stream ? (hipStream_t)stream : s->stream;
+    return render_impl(s, cam, opts, (float*)d_rgb_out, (uint8_t*)d_rgb8_out, st, stats);
+}
+
+int rtx_render(rtx_scene* s, const rtx_camera* cam, const rtx_opts* opts, float* rgb_out, rtx_stats* stats) {
+    if (!s) return fail(RTX_E_INVALID, "scene is NULL");
+    if (!rgb_out) return fail(RTX_E_INVALID, "rgb_out is NULL");
+    int rc = check_camera(cam);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(s->device));
+    const RowPlan plan = plan_rows(cam, opts);
+    const size_t rows = (opts && opts->compact_rows) ? plan.rows_local : cam->vertical_size;
+    const size_t floats = rows * cam->horizontal_size * 3;
+    rc = ensure_canvas(s, floats ? floats : 1);
+    if (rc) return rc;
+    rc = render_impl(s, cam, opts, s->d_canvas, nullptr, s->stream, stats);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(rgb_out, s->d_canvas, floats * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return RTX_OK;
+}
+
+int rtx_color_at(rtx_scene* s, const float* origins, const float* directions, uint32_t n, uint32_t depth, float* rgb_out) {
+    if (!s) return fail(RTX_E_INVALID, "scene is NULL");
+    if (n == 0) return RTX_OK;
+    if (!origins || !directions || !rgb_out) return fail(RTX_E_INVALID, "NULL ray or output buffer");
+    if (depth == 0) depth = kMaxDepth;
+    if (depth > kMaxDepth) return fail(RTX_E_INVALID, "depth %u exceeds ray_depth_limit %d", depth, kMaxDepth);
+    if (n > (1u << 22)) return fail(RTX_E_INVALID, "at most %u rays per call", 1u << 22);
+    HIP_TRY(hipSetDevice(s->device));
+    int rc = ensure_work(s, n);
+    if (rc) return rc;
+    rc = ensure_canvas(s, (size_t)n * 3);
+    if (rc) return rc;
+    hipStream_t st = s->stream;
+    std::vector<uint2> links(n);
+    for (uint32_t i = 0; i < n; ++i) links[i] = make_uint2(i, 0x3F800000u /* weight 1.0f, unused at the root */);
+    HIP_TRY(hipMemcpyAsync(s->q_org[0], origins, (size_t)n * 16, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(s->q_dir[0], directions, (size_t)n * 16, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(s->q_link[0], links.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(s->d_counters, 0, sizeof(Counters), st));
+    HIP_TRY(hipMemsetAsync(s->d_totals, 0, sizeof(Totals), st));
+    Params p;
+    fill_scene_params(s, p, depth);
+    p.canvas = s->d_canvas;
+    p.root_count = n;
+    rc = run_levels<false>(s, p, n, n, st, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(rgb_out, s->d_canvas, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return RTX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,169 @@
+"""Helpers shared by the tests: deep byte images of rt_world, random scene builders."""
+import ctypes as C
+import importlib
+
+import numpy as np
+
+rta = importlib.import_module("ray-tracer_amd")
+st = rta.st
+
+_LISTS = ["spheres", "planes", "cubes", "cylinders", "cones", "triangles"]
+
+
+def _arr_bytes(ptr, n):
+    if n == 0:
+        return b""
+    return C.string_at(ptr, n * C.sizeof(ptr._type_))
+
+
+def group_bytes(g):
+    out = [bytes(g.transform), bytes(C.c_int32(1 if g.has_bounding_box else 0))]
+    if g.has_bounding_box:
+        out.append(bytes(g.bounding_box))
+    for name in _LISTS:
+        out.append(_arr_bytes(getattr(g, name), getattr(g, "n_" + name)))
+    for i in range(g.n_subgroups):
+        out.append(group_bytes(g.subgroups[i]))
+    return b"|".join(out)
+
+
+def world_bytes(w):
+    """Every byte the renderer can see of an rt_world, pointers followed."""
+    out = [bytes(w.light_position), bytes(w.light_intensity)]
+    for name in _LISTS:
+        out.append(_arr_bytes(getattr(w, name), getattr(w, "n_" + name)))
+    for i in range(w.n_groups):
+        out.append(group_bytes(w.groups[i]))
+    return b"|".join(out)
+
+
+def mat(rows):
+    return st.Mat4.from_rows(rows)
+
+
+def mat_mul(a, b):
+    out = st.Mat4()
+    rta.lib().rt_mat_mul(C.byref(a), C.byref(b), C.byref(out))
+    return out
+
+
+def translation(x, y, z):
+    out = st.Mat4()
+    rta.lib().rt_mat_translation(x, y, z, C.byref(out))
+    return out
+
+
+def scaling(x, y, z):
+    out = st.Mat4()
+    rta.lib().rt_mat_scaling(x, y, z, C.byref(out))
+    return out
+
+
+def rotation(axis, r):
+    out = st.Mat4()
+    getattr(rta.lib(), "rt_mat_rotation_" + axis)(r, C.byref(out))
+    return out
+
+
+def compose(*ms):
+    acc = ms[0]
+    for m in ms[1:]:
+        acc = mat_mul(acc, m)
+    return acc
+
+
+def random_transform(rng, spread=2.0):
+    t = translation(*[float(v) for v in rng.uniform(-spread, spread, 3)])
+    r = compose(rotation("x", float(rng.uniform(-3, 3))), rotation("y", float(rng.uniform(-3, 3))),
+                rotation("z", float(rng.uniform(-3, 3))))
+    s = scaling(*[float(v) for v in rng.uniform(0.3, 1.5, 3)])
+    return compose(t, r, s)
+
+
+def random_material(rng, fancy=True):
+    m = st.default_material()
+    m.color[:] = [float(v) for v in rng.uniform(0, 1, 3)]
+    m.ambient = float(rng.uniform(0, 0.4))
+    m.diffuse = float(rng.uniform(0.2, 1))
+    m.specular = float(rng.uniform(0, 1))
+    m.shininess = float(rng.choice([10.0, 50.0, 200.0, 300.0]))
+    if fancy:
+        kind = rng.integers(0, 4)
+        if kind == 1:
+            m.reflective = float(rng.uniform(0.1, 0.9))
+        elif kind == 2:
+            m.transparency = float(rng.uniform(0.3, 1.0))
+            m.refractive_index = float(rng.choice([1.0003, 1.33, 1.5, 2.417]))
+        elif kind == 3:
+            m.reflective = float(rng.uniform(0.1, 0.9))
+            m.transparency = float(rng.uniform(0.3, 1.0))
+            m.refractive_index = float(rng.choice([1.0003, 1.33, 1.5, 2.417]))
+        if rng.random() < 0.4:
+            m.has_pattern = 1
+            m.pattern.a[:] = [float(v) for v in rng.uniform(0, 1, 3)]
+            m.pattern.b[:] = [float(v) for v in rng.uniform(0, 1, 3)]
+            m.pattern.color_map = int(rng.integers(0, 4))
+            m.pattern.transform = compose(rotation("y", float(rng.uniform(-1, 1))),
+                                          scaling(*[float(v) for v in rng.uniform(0.2, 1.0, 3)]))
+    return m
+
+
+def random_shape(rng, kind, fancy=True):
+    a = st.Attrs()
+    a.transform = random_transform(rng)
+    a.material = random_material(rng, fancy)
+    if kind == "spheres":
+        return st.Sphere(a)
+    if kind == "planes":
+        return st.Plane(a)
+    if kind == "cubes":
+        return st.Cube(a)
+    if kind in ("cylinders", "cones"):
+        lo = float(rng.uniform(-1.5, 0))
+        hi = float(rng.uniform(0.2, 1.5))
+        closed = int(rng.integers(0, 2))
+        return (st.Cylinder if kind == "cylinders" else st.Cone)(a, lo, hi, closed)
+    pts = rng.uniform(-1.5, 1.5, (3, 3))
+    t = st.Triangle()
+    p = [(C.c_float * 4)(float(q[0]), float(q[1]), float(q[2]), 1.0) for q in pts]
+    rta.lib().rt_triangle_init(p[0], p[1], p[2], C.byref(t))
+    t.common_attrs = a
+    if rng.random() < 0.7:
+        t.common_attrs.transform = st.identity()
+    return t
+
+
+def random_world(seed, n_shapes=8, groups=0, fancy=True):
+    """A seeded random scene using every shape type; returns (world, keepalive)."""
+    rng = np.random.default_rng(seed)
+    kinds = ["spheres", "planes", "cubes", "cylinders", "cones", "triangles"]
+    shapes = {k: [] for k in kinds}
+    for i in range(n_shapes):
+        k = kinds[i % 6] if i < 6 else kinds[int(rng.integers(0, 6))]
+        shapes[k].append(random_shape(rng, k, fancy))
+    keep = []
+    glist = []
+    for gi in range(groups):
+        sub_shapes = {k: [random_shape(rng, k, fancy)] for k in rng.choice(kinds, 2, replace=False)}
+        sub = st.make_group(transform=random_transform(rng, 0.5), keep=keep, **sub_shapes)
+        if rng.random() < 0.5:
+            b = st.Bounds()
+            rta.lib().rt_bound_group(C.byref(sub), C.byref(b))
+            sub.has_bounding_box = 1
+            sub.bounding_box = b
+        own = {k: [random_shape(rng, k, fancy)] for k in rng.choice(kinds, 3, replace=False)}
+        g = st.make_group(transform=random_transform(rng, 1.0), subgroups=[sub], keep=keep, **own)
+        if gi % 2 == 0:
+            b = st.Bounds()
+            rta.lib().rt_bound_group(C.byref(g), C.byref(b))
+            g.has_bounding_box = 1
+            g.bounding_box = b
+        glist.append(g)
+    light = [float(v) for v in rng.uniform(-6, 6, 3)] + [1.0]
+    light[1] = abs(light[1]) + 3
+    w, keep = st.make_world(light, [float(v) for v in rng.uniform(0.6, 1.0, 3)], groups=glist, keep=keep, **shapes)
+    return w, keep
+
+
+def default_camera(w=96, h=64, fov=1.0, frm=(0, 1.5, -7, 1), to=(0, 0, 0, 1), up=(0, 1, 0, 0)):
+    return rta.camera(w, h, fov, frm, to, up)

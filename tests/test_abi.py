@@ -1,0 +1,87 @@
+"""The C-ABI shared library loads here (no GPU) and exports every symbol the headers declare;
+the ctypes mirrors match the C struct sizes; rendering fails loudly without a device."""
+import ctypes as C
+import importlib
+import os
+import re
+
+import pytest
+
+rta = importlib.import_module("ray-tracer_amd")
+st = rta.st
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    names = set()
+    for hdr in ("rt_api.h", "rtx.h"):
+        text = open(os.path.join(ROOT, "include", hdr)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names |= set(re.findall(r"\b(rtx?_[a-z0-9_]+)\s*\(", text))
+    return names
+
+
+def test_library_exports_every_declared_symbol():
+    L = rta.lib()
+    declared = declared_symbols()
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(L, name), "missing export: " + name
+    assert declared == set(rta.SYMBOLS), declared ^ set(rta.SYMBOLS)
+
+
+def test_struct_sizes_match_the_headers():
+    # sizes computed from include/rt_scene.h / rtx.h field lists (all 4-byte scalars, 8-byte pointers)
+    assert C.sizeof(st.Mat4) == 64
+    assert C.sizeof(st.Pattern) == 24 + 64 + 4
+    assert C.sizeof(st.Material) == 12 + 4 + 92 + 7 * 4
+    assert C.sizeof(st.Attrs) == 64 + C.sizeof(st.Material)
+    assert C.sizeof(st.Cylinder) == C.sizeof(st.Attrs) + 12
+    assert C.sizeof(st.Triangle) == C.sizeof(st.Attrs) + 96
+    assert C.sizeof(rta.RtxShape) == 160
+    assert C.sizeof(rta.RtxMaterial) == 48
+    assert C.sizeof(rta.RtxPattern) == 96
+    assert C.sizeof(rta.RtxNode) == 48
+    assert C.sizeof(rta.RtxCamera) == 20 + 64
+    assert C.sizeof(rta.RtxOpts) == 32
+
+
+def test_defaults_match_reference_material():
+    m = st.Material()
+    rta.lib().rt_default_material(C.byref(m))
+    d = st.default_material()
+    assert bytes(m) == bytes(d)  # src/material.zig:10-37
+
+
+def test_ppm_byte_rule():
+    L = rta.lib()
+    assert [L.rt_ppm_byte(v) for v in (-1.0, 0.0, 0.5 / 255, 0.49 / 255, 1.0, 2.0)] == [0, 0, 1, 0, 255, 255]
+
+
+def test_canvas_to_ppm_layout():
+    import numpy as np
+
+    canvas = np.array([[[1, 0, 0], [0, 0.5, 0]], [[0, 0, 1.5], [-0.5, 0, 1]]], dtype=np.float32)
+    need = rta.lib().rt_canvas_to_ppm(rta.fptr(canvas), 2, 2, None, 0)
+    buf = C.create_string_buffer(need)
+    rta.lib().rt_canvas_to_ppm(rta.fptr(canvas), 2, 2, buf, need)
+    assert buf.raw == b"P3\n2 2\n255\n255 0 0\n0 128 0\n0 0 255\n0 0 255\n"  # canvas.zig:42-50
+
+
+def _gpu():
+    try:
+        import torch
+
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+@pytest.mark.skipif(_gpu(), reason="checks the no-device error path")
+def test_render_fails_loudly_without_a_gpu():
+    s = rta.Sample("cone", 16, 16)
+    with pytest.raises(rta.RtxError) as e:
+        rta.Scene(s.world)
+    assert e.value.code == -2  # RTX_E_NO_DEVICE: no CPU fallback exists
+    with pytest.raises(rta.RtxError):
+        rta.render(s.camera, s.world)

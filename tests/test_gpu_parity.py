@@ -1,0 +1,210 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same inputs.
+
+Bar (BASELINE.json north_star): PPM bytes within +-1 LSB on >= 99.9 % of pixels.  What the
+implementation actually delivers is stronger — the f32 canvas is bit-identical to the oracle
+(same IEEE operations in the same order; pow restated identically on both sides) — and the
+tests assert that stronger property, with the north-star bar as the fallback message.
+"""
+import ctypes as C
+import importlib
+
+import numpy as np
+import pytest
+
+import oracle_lib as o
+import scene_util as su
+
+rta = importlib.import_module("ray-tracer_amd")
+st = rta.st
+
+pytestmark = pytest.mark.gpu
+
+SMALL = {
+    "sphere_world": (200, 100), "glass_spheres": (120, 120), "fresnel": (160, 80), "cylinder_world": (200, 100),
+    "cone": (128, 128), "cube": (128, 128), "reflective_floor": (128, 128), "skewed_triangle": (128, 128),
+    "striped_scene": (128, 128), "sphere_on_plane": (128, 128),
+}
+
+
+def compare(gpu, ref, what):
+    assert gpu.shape == ref.shape
+    same = gpu.view(np.uint32) == ref.view(np.uint32)
+    both_zero = (gpu == 0) & (ref == 0)  # +0 vs -0 print the same
+    exact = (same | both_zero).all(axis=-1)
+    pb = np.abs(rta.to_ppm_bytes(gpu).astype(np.int32) - o.to_ppm_bytes(ref).astype(np.int32)).max(axis=-1)
+    msg = "%s: bit-exact pixels %.4f%%, PPM exact %.4f%%, within 1 LSB %.4f%%, max |diff| %g" % (
+        what, 100 * exact.mean(), 100 * (pb == 0).mean(), 100 * (pb <= 1).mean(), np.abs(gpu - ref).max())
+    assert (pb <= 1).mean() >= 0.999, "north-star bar missed: " + msg
+    assert exact.all(), msg
+
+
+@pytest.mark.parametrize("name", rta.SAMPLES)
+def test_sample_matches_oracle(name):
+    w, h = SMALL[name]
+    s = rta.Sample(name, w, h)
+    ref, counts = o.render(s.camera, s.world)
+    scene = rta.Scene(s.world)
+    gpu, stats = scene.render(s.camera)
+    compare(gpu, ref, name)
+    assert (stats.rays_primary, stats.rays_shadow, stats.rays_secondary) == (counts.primary, counts.shadow, counts.secondary)
+    scene.close()
+
+
+def test_by_value_drop_in_rt_render():
+    s = rta.Sample("cylinder_world", 96, 48)
+    ref, counts = o.render(s.camera, s.world)
+    gpu, c = rta.render(s.camera, s.world)
+    compare(gpu, ref, "rt_render")
+    assert c.total == counts.total
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_world_matches_oracle(seed):
+    w, keep = su.random_world(seed, n_shapes=6 + seed, groups=seed % 3)
+    cam = su.default_camera(96, 64)
+    ref, counts = o.render(cam, w)
+    scene = rta.Scene(w)
+    gpu, stats = scene.render(cam)
+    compare(gpu, ref, "random world %d" % seed)
+    assert stats.rays_total == counts.total
+    scene.close()
+
+
+def test_color_at_matches_oracle_including_rays_from_inside():
+    s = rta.Sample("glass_spheres")
+    scene = rta.Scene(s.world)
+    rng = np.random.default_rng(2)
+    origins = np.concatenate([rng.uniform(-0.4, 0.4, (40, 3)), rng.uniform(-3, 3, (40, 3))]).astype(np.float32)
+    origins = np.concatenate([origins, np.ones((80, 1), np.float32)], axis=1)
+    d = rng.normal(size=(80, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    dirs = np.concatenate([d, np.zeros((80, 1), np.float32)], axis=1)
+    gpu = scene.color_at(origins, dirs)
+    ref = np.stack([o.color_at(s.world, origins[i], dirs[i]) for i in range(80)])
+    compare(gpu[None], ref[None], "color_at")
+    scene.close()
+
+
+def test_duplicate_intersections_cancel_in_the_n1_walk():
+    """Tangent sphere behind the ray origin: its two equal roots cancel (std.meta.eql on whole
+    Intersections, intersection.zig:126-137), so n1 comes from the entry before them."""
+    glass = st.default_attrs()
+    glass.material.transparency = 0.9
+    glass.material.reflective = 0.5
+    glass.material.refractive_index = 1.5
+    front = st.Sphere(glass)
+    front.common_attrs.transform = su.translation(0, 0, 5)
+    dense = st.default_attrs()
+    dense.material.refractive_index = 2.4
+    dense.material.transparency = 0.5
+    tangent = st.Sphere(dense)
+    tangent.common_attrs.transform = su.translation(1, 0, -5)  # ray x=0 is tangent at t=-5 (disc == 0)
+    behind = st.default_attrs()
+    behind.material.refractive_index = 1.2
+    behind.material.transparency = 0.5
+    wall = st.Plane(behind)
+    wall.common_attrs.transform = su.compose(su.translation(0, 0, -8), su.rotation("x", float(np.float32(np.pi / 2))))
+    floor = st.Plane(st.default_attrs())
+    floor.common_attrs.transform = su.translation(0, -3, 0)
+    floor.common_attrs.material.has_pattern = 1
+    floor.common_attrs.material.pattern.a[:] = [1, 0, 0]
+    floor.common_attrs.material.pattern.b[:] = [0, 1, 0]
+    floor.common_attrs.material.pattern.color_map = st.PATTERN_CHECKER
+    w, keep = st.make_world([2, 6, -3, 1], [1, 1, 1], spheres=[front, tangent], planes=[wall, floor])
+    origins = np.array([[0, 0, 0, 1], [0, 0.1, 0, 1], [0.05, 0, 0, 1]], np.float32)
+    dirs = np.array([[0, 0, 1, 0]] * 3, np.float32)
+    scene = rta.Scene(w)
+    gpu = scene.color_at(origins, dirs)
+    ref = np.stack([o.color_at(w, origins[i], dirs[i]) for i in range(3)])
+    compare(gpu[None], ref[None], "tangent duplicate")
+    # twin shapes (byte-identical) cancel each other as well
+    w2, keep2 = st.make_world([2, 6, -3, 1], [1, 1, 1], spheres=[front, tangent, tangent], planes=[wall, wall, floor])
+    scene2 = rta.Scene(w2)
+    gpu = scene2.color_at(origins, dirs)
+    ref = np.stack([o.color_at(w2, origins[i], dirs[i]) for i in range(3)])
+    compare(gpu[None], ref[None], "twin shapes")
+    scene.close()
+    scene2.close()
+
+
+def test_rows_quirk_leaves_remainder_rows_black():
+    s = rta.Sample("sphere_world", 100, 70)  # 8*floor(70/8) = 64 rows rendered (camera.zig:87-88)
+    scene = rta.Scene(s.world)
+    gpu, stats = scene.render(s.camera)
+    ref, _ = o.render(s.camera, s.world)
+    compare(gpu, ref, "rows quirk")
+    assert stats.rows_rendered == 64 and not gpu[64:].any() and gpu[:64].any()
+    full, stats = scene.render(s.camera, rows_quirk=False)
+    ref, _ = o.render(s.camera, s.world, rows_quirk=False)
+    compare(full, ref, "no quirk")
+    scene.close()
+
+
+def test_depth_option_limits_recursion():
+    s = rta.Sample("glass_spheres", 64, 64)
+    scene = rta.Scene(s.world)
+    _, s5 = scene.render(s.camera)
+    _, s2 = scene.render(s.camera, depth=2)
+    assert s2.level_rays[3] == 0 and s5.level_rays[5] > 0 and s2.level_rays[1] == s5.level_rays[1]
+    scene.close()
+
+
+# ---- size-independent properties at BASELINE.json's full sizes -----------------------------
+
+def test_full_size_is_independent_of_batching_and_strips():
+    s = rta.Sample("glass_spheres", 1920, 1080)
+    scene = rta.Scene(s.world)
+    a, sa = scene.render(s.camera)
+    b, sb = scene.render(s.camera, batch_pixels=1 << 16)
+    assert a.tobytes() == b.tobytes() and sa.rays_total == sb.rays_total
+    # four interleaved strip sets (what four ranks would render) reassemble the same canvas bit for bit
+    acc = np.zeros_like(a)
+    rays = 0
+    rows = 0
+    for r in range(4):
+        part, sp = scene.render(s.camera, strips=(16, 4, r))
+        assert not (acc.astype(bool) & part.astype(bool)).any()
+        acc += part
+        rays += sp.rays_total
+        rows += sp.rows_rendered
+        comp, _ = scene.render(s.camera, strips=(16, 4, r), compact_rows=True)
+        ys = [y for y in range(1080) if (y // 16) % 4 == r]
+        assert comp.shape[0] == len(ys) == rta.rows_for(s.camera, strips=(16, 4, r))
+        assert comp.tobytes() == a[ys].tobytes()
+    assert acc.tobytes() == a.tobytes() and rays == sa.rays_total and rows == 1080
+    # sampled rows agree with the oracle (every 135th row keeps the CPU side to seconds)
+    ref, _ = o.render(s.camera, s.world, row_step=135)
+    ys = [y for y in range(1080) if (y % 135) == 0]
+    compare(a[ys], ref[ys], "1920x1080 sampled rows")
+    scene.close()
+
+
+def test_device_canvas_and_u8_quantisation():
+    import torch
+
+    s = rta.Sample("cylinder_world", 256, 128)
+    scene = rta.Scene(s.world)
+    host, _ = scene.render(s.camera)
+    rgb = torch.zeros((128, 256, 3), dtype=torch.float32, device="cuda")
+    rgb8 = torch.zeros((128, 256, 3), dtype=torch.uint8, device="cuda")
+    stats = scene.render_device(s.camera, rgb.data_ptr(), rgb8.data_ptr(), want_stats=True)
+    torch.cuda.synchronize()
+    assert stats.rays_primary == 256 * 128
+    assert rgb.cpu().numpy().tobytes() == host.tobytes()
+    assert np.array_equal(rgb8.cpu().numpy(), rta.to_ppm_bytes(host))  # canvas.zig:45-47
+    scene.close()
+
+
+def test_invalid_arguments_are_rejected():
+    s = rta.Sample("cone", 32, 32)
+    flat = rta.FlatScene(s.world)
+    flat.desc.shapes[0].material = 99
+    h = C.c_void_p()
+    assert rta.lib().rtx_scene_create(C.byref(flat.desc), 0, C.byref(h)) == -1
+    assert b"material" in rta.lib().rtx_last_error()
+    scene = rta.Scene(s.world)
+    with pytest.raises(rta.RtxError):
+        scene.render(s.camera, depth=6)
+    with pytest.raises(rta.RtxError):
+        scene.render(s.camera, strips=(8, 2, 2))
+    scene.close()
