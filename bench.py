@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json's metric on its configs[1] workload.
+
+A step = one pass of the hot path (`Camera.render -> World.colorAt`) over one batch of
+synthetic input: the reference's glass_spheres AND fresnel scenes, each rendered at
+1920x1080 with reflection/refraction depth 5 (BASELINE.json configs[1]), scenes already
+resident in HBM, canvases left on the device (f32 + the u8 quantisation of canvas.zig).
+metric = Mrays/s, a ray being one colorAtInternal or one isShadowed call.
+
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): every rank holds the scenes,
+renders the 16-row strips s with s % N == rank of each frame, and the u8 strips are gathered
+on rank 0 over RCCL — the same frames split N ways, i.e. strong scaling.  Time is the max
+over ranks between two barrier+synchronize pairs.
+
+Also reported in the same JSON line: `roofline` for the dominant kernel (k_trace_shade:
+algorithmic flops from SURVEY §8d's table x device event counts, over the HIP-event duration
+of its launches inside the timed region) and `cpu_baseline` (the oracle — a C port of the
+reference's algorithm, 8 static row bands like src/camera.zig:87-99 — timed on this box on
+a bounded row sample of the same workload; rank 0, N = 1 only).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+import torch
+
+rta = importlib.import_module("ray-tracer_amd")
+
+WIDTH, HEIGHT = 1920, 1080
+SCENES = ["glass_spheres", "fresnel"]
+STRIP_ROWS = 16
+VALU_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz, one flop per VALU op: FMA
+                         # contraction is forbidden by parity, so mul and add issue separately
+                         # (the FMA/packed peak is 157.3 TFLOP/s; DESIGN.md "Roofline")
+
+# SURVEY.md §8(d) flop table (add/sub/mul/div/sqrt = 1, fma = 2, pow = 1, compares = 0;
+# 4-lane dot = 7, mat-vec = 28).
+F_RAYGEN = 80
+F_XFORM = 56
+F_TEST = {0: 44, 1: 2, 2: 16, 3: 48, 4: 58, 5: 55}  # sphere, plane, cube, cylinder, cone, triangle
+F_PREPARE = 98       # prepareComputations incl. position
+F_SHADOW_SETUP = 24
+F_LIGHTING = 70
+F_PATTERN = 62       # object-space transform + pattern-space transform + pattern
+F_REFRACT = 60       # refraction set-up + Schlick
+F_COMBINE = 12
+
+
+def shape_test_flops(world):
+    """Flops to test one ray against every shape of a group-free world."""
+    counts = [world.n_spheres, world.n_planes, world.n_cubes, world.n_cylinders, world.n_cones, world.n_triangles]
+    return sum(n * (F_XFORM + F_TEST[t]) for t, n in enumerate(counts))
+
+
+def trace_shade_flops(world, st):
+    """Algorithmic flops of all k_trace_shade launches of one frame, from device event counts."""
+    per_ray = shape_test_flops(world)
+    rays = sum(st.level_rays[l] for l in range(6))
+    hits = st.rays_shadow
+    f = st.rays_primary * F_RAYGEN
+    f += rays * per_ray                       # closest-hit traversal
+    f += hits * (F_PREPARE + F_SHADOW_SETUP + per_ray + F_LIGHTING + F_COMBINE)  # shadow any-hit is a full pass
+    f += st.hits_patterned * F_PATTERN
+    f += st.hits_transparent * F_REFRACT
+    return f
+
+
+def cpu_baseline(samples):
+    """The oracle (C port of the reference algorithm) on a bounded row sample of the workload."""
+    import oracle_lib as o
+
+    row_step = 8
+    rays = 0
+    t0 = time.perf_counter()
+    for s in samples:
+        osamp = o.Sample(s.name, WIDTH, HEIGHT)
+        _, counts = o.render(osamp.camera, osamp.world, rows_quirk=True, row_step=row_step)
+        rays += counts.total
+    dt = time.perf_counter() - t0
+    return {
+        "value": rays / dt / 1e6, "unit": "Mrays/s", "cores": 8, "kind": "port",
+        "sample": "every %dth row of each 1920x1080 frame (%d rays, %.1f s), 8 threads on static row bands "
+                  "as src/camera.zig:87-99; C restatement of the Zig reference, not the Zig binary" % (row_step, rays, dt),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    n = args.gpus
+    dist = None
+    if n > 1:
+        import torch.distributed as dist
+
+        assert world == n, "launch with torch.distributed.run --nproc-per-node %d" % n
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    stream = torch.cuda.current_stream().cuda_stream
+
+    samples = [rta.Sample(name, WIDTH, HEIGHT) for name in SCENES]
+    scenes = [rta.Scene(s.world, device=dev.index) for s in samples]
+    cams = [rta.flatten_camera(s.camera) for s in samples]
+    strips = (STRIP_ROWS, n, rank) if n > 1 else None
+    rows = [rta.rows_for(c, strips=strips) for c in cams]
+    max_rows = -(-HEIGHT // STRIP_ROWS // n) * STRIP_ROWS if n > 1 else HEIGHT  # equal-size gather slots
+    rgb = [torch.zeros((max_rows, WIDTH, 3), dtype=torch.float32, device=dev) for _ in scenes]
+    rgb8 = [torch.zeros((max_rows, WIDTH, 3), dtype=torch.uint8, device=dev) for _ in scenes]
+    gathered = None
+    if n > 1 and rank == 0:
+        gathered = [[torch.zeros_like(rgb8[0]) for _ in range(n)] for _ in scenes]
+
+    def frame(profile):
+        for i, sc in enumerate(scenes):
+            sc.render_device(cams[i], rgb[i].data_ptr(), rgb8[i].data_ptr(), stream=stream, strips=strips,
+                             compact_rows=n > 1, profile=profile)
+            if n > 1:  # canvas gather: every peer sends its u8 strips straight to rank 0
+                dist.gather(rgb8[i], gathered[i] if rank == 0 else None, dst=0)
+
+    def fence():
+        if n > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # Ray counts of this rank's share (deterministic per frame): one counted pass, untimed.
+    stats = [sc.render_device(cams[i], rgb[i].data_ptr(), None, stream=stream, strips=strips, compact_rows=n > 1,
+                              want_stats=True) for i, sc in enumerate(scenes)]
+    rays_local = sum(s.rays_total for s in stats)
+
+    for _ in range(args.warmup):
+        frame(False)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        frame(True)
+    fence()
+    dt = time.perf_counter() - t0
+
+    prof = [sc.profile_collect() for sc in scenes]
+    t = torch.tensor([dt, float(rays_local)], dtype=torch.float64, device=dev)
+    if n > 1:
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        dt, rays_step = float(tmax[0]), float(t[1])
+    else:
+        rays_step = float(rays_local)
+
+    if rank == 0:
+        ms_trace = sum(p.ms_trace_shade for p in prof)
+        launches = sum(p.launches_trace_shade for p in prof)
+        flops_step = sum(trace_shade_flops(s.world, st) for s, st in zip(samples, stats))
+        avg_ms = ms_trace / max(launches, 1)
+        flops_per_launch = flops_step * args.steps / max(launches, 1)
+        achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        out = {
+            "metric": "Mrays/s (primary+shadow+secondary)",
+            "value": rays_step * args.steps / dt / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "glass_spheres + fresnel (samples/*.zig scenes) at 1920x1080, depth 5, one step = both frames",
+                "rays_per_step": int(rays_step), "frame_ms": dt / args.steps * 1e3 / len(SCENES),
+                "parallelism": "1 GPU" if n == 1 else "%d ranks x 16-row strips, RCCL gather of the u8 canvas" % n,
+            },
+            "roofline": {
+                "bound": "valu", "kernel": "k_trace_shade",
+                "achieved": achieved, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / VALU_PEAK_TFLOPS,
+                "traffic": None,
+                "flops_per_launch": flops_per_launch, "avg_launch_ms": avg_ms, "launches": launches,
+                "share_of_step": ms_trace / (dt * 1e3) if dt > 0 else None,
+                "note": "f32 VALU roofline (no MFMA: divergent per-lane scalar math); peak = non-FMA issue rate; "
+                        "rank 0's launches; HBM traffic per launch is in profiles/ (PMC pass)",
+            },
+        }
+        if n == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(samples)
+        print(json.dumps(out), flush=True)
+    for sc in scenes:
+        sc.close()
+    if n > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

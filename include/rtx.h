@@ -151,6 +151,9 @@ typedef struct rtx_stats {
     uint64_t rays_secondary; /* colorAtInternal calls below the root */
     uint64_t level_rays[6];  /* rays traced per depth level */
     uint64_t nodes;          /* interior ray-tree nodes stored for the combine pass */
+    uint64_t level_hits[6];  /* hits per depth level (each one is an isShadowed call) */
+    uint64_t hits_patterned; /* hits whose material has a pattern (Pattern.atShape evaluated) */
+    uint64_t hits_transparent; /* hits on transparency != 0 (refraction set-up evaluated) */
     float    ms_total;       /* device time of the whole call (HIP events on the render stream) */
     float    ms_trace_shade; /* sum over launches of the trace+shade kernel (profile=1) */
     float    ms_combine;     /* sum over launches of the combine kernel (profile=1) */
@@ -188,6 +191,14 @@ int rtx_render(rtx_scene* scene, const rtx_camera* cam, const rtx_opts* opts, fl
  */
 int rtx_render_device(rtx_scene* scene, const rtx_camera* cam, const rtx_opts* opts, void* d_rgb_out,
                       void* d_rgb8_out, void* stream, rtx_stats* stats);
+
+/*
+ * With opts->profile = 1 every kernel launch is bracketed by HIP events on the render
+ * stream.  A call that passes `stats` reads them back itself; calls that do not (the
+ * asynchronous frame loop) leave them pending, and this collects everything recorded since
+ * the last read into the ms_* / launches_* fields of `out` (synchronises the stream).
+ */
+int rtx_profile_collect(rtx_scene* scene, rtx_stats* out);
 
 /* colorAt() — src/world.zig:81-83 — for n rays (origins/directions: n*4 f32; rgb: n*3 f32), host buffers. */
 int rtx_color_at(rtx_scene* scene, const float* origins, const float* directions, uint32_t n, uint32_t depth,

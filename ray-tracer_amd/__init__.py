@@ -73,6 +73,7 @@ class RtxOpts(C.Structure):
 class RtxStats(C.Structure):
     _fields_ = [("rays_primary", C.c_uint64), ("rays_shadow", C.c_uint64), ("rays_secondary", C.c_uint64),
                 ("level_rays", C.c_uint64 * 6), ("nodes", C.c_uint64),
+                ("level_hits", C.c_uint64 * 6), ("hits_patterned", C.c_uint64), ("hits_transparent", C.c_uint64),
                 ("ms_total", f32), ("ms_trace_shade", f32), ("ms_combine", f32),
                 ("launches_trace_shade", u32), ("launches_combine", u32), ("rows_rendered", u32), ("reserved", u32)]
 
@@ -89,6 +90,7 @@ _SIGNATURES = [
     ("rtx_rows_for", C.c_int, [P(RtxCamera), P(RtxOpts), P(u32)]),
     ("rtx_render", C.c_int, [C.c_void_p, P(RtxCamera), P(RtxOpts), P(f32), P(RtxStats)]),
     ("rtx_render_device", C.c_int, [C.c_void_p, P(RtxCamera), P(RtxOpts), C.c_void_p, C.c_void_p, C.c_void_p, P(RtxStats)]),
+    ("rtx_profile_collect", C.c_int, [C.c_void_p, P(RtxStats)]),
     ("rtx_color_at", C.c_int, [C.c_void_p, P(f32), P(f32), u32, u32, P(f32)]),
     ("rtx_last_error", C.c_char_p, []),
     ("rt_camera_init", None, [u32, u32, f32, P(f32), P(f32), P(f32), P(st.Camera)]),
@@ -271,6 +273,12 @@ class Scene:
         _check(L.rtx_render_device(self.handle, C.byref(rc), C.byref(opts), C.c_void_p(d_rgb),
                                    C.c_void_p(d_rgb8) if d_rgb8 else None, C.c_void_p(stream) if stream else None,
                                    C.byref(stats) if stats is not None else None))
+        return stats
+
+    def profile_collect(self):
+        """Sum the pending per-launch HIP-event timings (profile=True frames) -> RtxStats."""
+        stats = RtxStats()
+        _check(lib().rtx_profile_collect(self.handle, C.byref(stats)))
         return stats
 
     def color_at(self, origins, directions, depth=0):

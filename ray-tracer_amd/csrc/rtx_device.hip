@@ -69,17 +69,43 @@ struct V4 {
     float x, y, z, w;
 };
 
+// Scene records are read-only for the lifetime of a launch.  Reading the wave-uniform ones
+// (the shape / node being tested by the whole wave) through the constant address space makes
+// hipcc emit scalar loads (s_load) into SGPRs instead of 64 identical vector loads.
+#define RT_CONST __attribute__((address_space(4)))
+template <class T>
+__device__ __forceinline__ const RT_CONST T* as_const(const T* p) {
+    return (const RT_CONST T*)(uintptr_t)p;
+}
+
+// The ray queues and node arrays are split into kShards independent shards so that slot
+// allocation (one returning atomic per wave and iteration) never funnels the whole chip
+// through one word: wave w works for shard w % kShards at every level, reads that shard's
+// rays and appends its children to the same shard.  A single counter word saturates near
+// 88 returning atomics per microsecond on MI355X (MI355X_MICROARCH.md, row "dequeue"), which
+// made the unsharded version 93 % SQ_WAIT_ANY (profiles/r01_*).
+constexpr uint32_t kShards = 64;
+
+struct ShardCounters {  // one 128-byte line per shard
+    // per level d: low 32 bits = rays queued for level d + 1, high 32 bits = interior nodes at d
+    unsigned long long alloc[kLevels];
+    unsigned long long pad[16 - kLevels];
+};
+
 struct Counters {
-    uint32_t queue_count[kLevels + 1];  // rays queued for level d (level 0 is implicit)
-    uint32_t node_count[kLevels];       // interior nodes allocated at level d
+    ShardCounters shard[kShards];
     uint32_t hits[kLevels];             // hits at level d == isShadowed calls
+    uint32_t hits_patterned;
+    uint32_t hits_transparent;
     uint32_t pad;
 };
 
 struct Totals {
     unsigned long long level_rays[kLevels];
-    unsigned long long hits;
+    unsigned long long level_hits[kLevels];
     unsigned long long nodes;
+    unsigned long long hits_patterned;
+    unsigned long long hits_transparent;
 };
 
 struct Params {
@@ -112,6 +138,7 @@ struct Params {
     float4* node_b;  // reflected slot rgb, weight towards the parent
     float4* node_c;  // refracted slot rgb, link bits
     uint32_t node_off[kLevels];
+    uint32_t shard_cap0;  // level-0 items per shard; a shard holds shard_cap0 << d rays / nodes at level d
 
     Counters* counters;
     float* canvas;        // root results land here: 3 floats per root index
@@ -238,7 +265,7 @@ __device__ __forceinline__ TMinMax check_axis(float mn, float mx, float origin, 
 }
 
 // bnd.intersect (src/bounds.zig:149-158): infinite-line slab test, no t range.
-__device__ __forceinline__ bool bounds_hit(const rtx_node& n, V4 o, V4 d) {
+__device__ __forceinline__ bool bounds_hit(const RT_CONST rtx_node& n, V4 o, V4 d) {
     const TMinMax x = check_axis(n.bounds_min[0], n.bounds_max[0], o.x, d.x);
     const TMinMax y = check_axis(n.bounds_min[1], n.bounds_max[1], o.y, d.y);
     const TMinMax z = check_axis(n.bounds_min[2], n.bounds_max[2], o.z, d.z);
@@ -271,9 +298,12 @@ __device__ __forceinline__ void offer_roots(V& v, uint32_t s, bool n1_visible, c
 // per lane.  o/d are the world-space ray; the object-space ray is r.transform(inverse)
 // (src/ray.zig:13-18) with all four lanes kept.
 template <class V>
-__device__ __forceinline__ void intersect_shape(V& v, const rtx_shape& sh, uint32_t s, V4 o, V4 d) {
-    const V4 ro = mul_mat(sh.inverse, o);
-    const V4 rd = mul_mat(sh.inverse, d);
+__device__ __forceinline__ void intersect_shape(V& v, const RT_CONST rtx_shape& sh, uint32_t s, V4 o, V4 d) {
+    float inv[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) inv[k] = sh.inverse[k];
+    const V4 ro = mul_mat(inv, o);
+    const V4 rd = mul_mat(inv, d);
     const bool n1_visible = !(sh.flags & RTX_SHAPE_N1_INVISIBLE);
     float t[4];
     bool ok[4] = {false, false, false, false};
@@ -414,8 +444,10 @@ __device__ __forceinline__ void intersect_shape(V& v, const rtx_shape& sh, uint3
 template <class V>
 __device__ __forceinline__ void traverse(V& v, const Params& p, V4 o, V4 d, bool lane_on) {
     uint32_t parked_until = lane_on ? 0u : kNone;  // node index at which this lane wakes up
+    const RT_CONST rtx_node* nodes = as_const(p.nodes);
+    const RT_CONST rtx_shape* shapes = as_const(p.shapes);
     for (uint32_t n = 0; n < p.n_nodes; ++n) {
-        const rtx_node& node = p.nodes[n];
+        const RT_CONST rtx_node& node = nodes[n];
         bool active = n >= parked_until && !v.done();
         if (active && node.has_bounds && !bounds_hit(node, o, d)) {
             parked_until = node.skip;
@@ -425,7 +457,7 @@ __device__ __forceinline__ void traverse(V& v, const Params& p, V4 o, V4 d, bool
         const uint32_t first = node.first_shape;
         const uint32_t last = first + node.n_shapes;
         for (uint32_t s = first; s < last; ++s) {
-            if (active) intersect_shape(v, p.shapes[s], s, o, d);
+            if (active) intersect_shape(v, shapes[s], s, o, d);
         }
     }
 }
@@ -567,18 +599,19 @@ __device__ __forceinline__ Color combine(Color surface, Color reflected, Color r
 
 // ------------------------------------------------------------- queues and delivery
 
-// One slot index per active lane, one atomic per wave.
-__device__ __forceinline__ uint32_t wave_alloc(uint32_t* counter, bool want) {
-    const unsigned long long mask = __ballot(want);
-    if (mask == 0ull) return 0;
-    const uint32_t total = __popcll(mask);
-    const uint32_t lane = __lane_id();
-    const uint32_t rank = __popcll(mask & ((1ull << lane) - 1ull));
-    uint32_t base = 0;
-    const uint32_t leader = __ffsll(static_cast<long long>(mask)) - 1;
-    if (lane == leader) base = atomicAdd(counter, total);
-    base = __shfl(base, leader);
-    return base + rank;
+// Slots for this wave's interior nodes and child rays with ONE returning atomic: the shard's
+// per-level word packs (nodes << 32) | rays.  Returns the shard-local bases.
+struct WaveAlloc {
+    uint32_t ray_base, node_base;
+};
+__device__ __forceinline__ WaveAlloc wave_alloc(unsigned long long* word, uint32_t n_rays, uint32_t n_nodes) {
+    WaveAlloc a{0u, 0u};
+    if (n_rays == 0u && n_nodes == 0u) return a;  // wave-uniform
+    unsigned long long old = 0ull;
+    if (__lane_id() == 0u) old = atomicAdd(word, (static_cast<unsigned long long>(n_nodes) << 32) | n_rays);
+    a.ray_base = __shfl(static_cast<uint32_t>(old), 0);
+    a.node_base = __shfl(static_cast<uint32_t>(old >> 32), 0);
+    return a;
 }
 
 // Hand a finished colour to whoever asked for it: the canvas at the root
@@ -608,17 +641,32 @@ template <bool GEN, bool TRACK>
 __global__ __launch_bounds__(256) void k_trace_shade(const Params p, const uint32_t level) {
     const bool root = level == 0;
     const uint32_t remaining = p.depth - level;  // `remaining` of colorAtInternal (src/world.zig:85)
-    uint32_t count;
-    if (GEN) count = p.tiles_x * ((p.n_rows + 7u) / 8u) * 64u;
-    else count = root ? p.root_count : p.counters->queue_count[level];
     const uint32_t qi = level & 1u, qo = qi ^ 1u;
-
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;  // a multiple of kShards (host guarantees)
+    const uint32_t shard = wave % kShards;
+    ShardCounters* sc = &p.counters->shard[shard];
 
-    uint32_t local_hits = 0;
-    for (uint32_t base = wave * 64u; base < count; base += n_waves * 64u) {
+    // Level 0 walks all items (wave w takes chunks w, w + n_waves, ...; chunk c belongs to
+    // shard c % kShards); deeper levels walk this wave's shard.
+    uint32_t count, first, stride, in_base;
+    if (root) {
+        count = GEN ? p.tiles_x * ((p.n_rows + 7u) / 8u) * 64u : p.root_count;
+        first = wave * 64u;
+        stride = n_waves * 64u;
+        in_base = 0u;
+    } else {
+        count = static_cast<uint32_t>(sc->alloc[level - 1]);
+        first = (wave / kShards) * 64u;
+        stride = (n_waves / kShards) * 64u;
+        in_base = shard * (p.shard_cap0 << level);
+    }
+    const uint32_t out_base = shard * (p.shard_cap0 << (level + 1u));
+    const uint32_t node_base = p.node_off[level] + shard * (p.shard_cap0 << level);
+
+    uint32_t local_hits = 0, local_patterned = 0, local_transparent = 0;
+    for (uint32_t base = first; base < count; base += stride) {
         const uint32_t i = base + lane;
         bool on = i < count;
         V4 o, d;
@@ -645,9 +693,9 @@ __global__ __launch_bounds__(256) void k_trace_shade(const Params p, const uint3
             d = normalize(sub(pixel, o));
             link = (p.compact_rows ? lrow : py) * p.width + px;
         } else if (on) {
-            const float4 qo4 = p.q_org[qi][i];
-            const float4 qd4 = p.q_dir[qi][i];
-            const uint2 ql = p.q_link[qi][i];
+            const float4 qo4 = p.q_org[qi][in_base + i];
+            const float4 qd4 = p.q_dir[qi][in_base + i];
+            const uint2 ql = p.q_link[qi][in_base + i];
             o = v4(qo4.x, qo4.y, qo4.z, qo4.w);
             d = v4(qd4.x, qd4.y, qd4.z, qd4.w);
             link = ql.x;
@@ -701,6 +749,8 @@ __global__ __launch_bounds__(256) void k_trace_shade(const Params p, const uint3
             reflectv = reflect(d, normal);
             reflective = m.reflective;
             transparency = m.transparency;
+            local_patterned += m.pattern >= 0 ? 1u : 0u;
+            local_transparent += m.transparency != 0.0f ? 1u : 0u;
             // shadeHitInternal (src/world.zig:54-79): Phong is evaluated at over_point.
             surface = lighting(p, m, sh, over_point, eye, normal, sv.found);
             // reflectedColorInternal (src/world.zig:126-143)
@@ -731,39 +781,56 @@ __global__ __launch_bounds__(256) void k_trace_shade(const Params p, const uint3
             const Color out = is_hit ? combine(surface, black, black, use_schlick, reflectance) : black;
             deliver(p, root, link, weight, out);
         }
-        const uint32_t node_local = wave_alloc(&p.counters->node_count[level], interior);
+        // One allocation per wave: reflected children first, refracted ones after them.
+        const unsigned long long m_node = __ballot(interior), m_refl = __ballot(spawn_reflect), m_refr = __ballot(spawn_refract);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        const uint32_t n_refl = __popcll(m_refl);
+        const WaveAlloc wa = wave_alloc(&sc->alloc[level], n_refl + __popcll(m_refr), __popcll(m_node));
         uint32_t node = 0;
         if (interior) {
-            node = p.node_off[level] + node_local;
+            node = node_base + wa.node_base + __popcll(m_node & below);
             p.node_a[node] = make_float4(surface.r, surface.g, surface.b, reflectance);
             p.node_b[node] = make_float4(0.0f, 0.0f, 0.0f, weight);
             uint32_t bits = (link & (kLinkIndexMask | kLinkSlotBit)) | (use_schlick ? kLinkSchlickBit : 0u);
             p.node_c[node] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(bits));
         }
-        const uint32_t r_slot = wave_alloc(&p.counters->queue_count[level + 1], spawn_reflect);
         if (spawn_reflect) {
-            p.q_org[qo][r_slot] = make_float4(over_point.x, over_point.y, over_point.z, over_point.w);
-            p.q_dir[qo][r_slot] = make_float4(reflectv.x, reflectv.y, reflectv.z, reflectv.w);
-            p.q_link[qo][r_slot] = make_uint2(node, __float_as_uint(reflective));
+            const uint32_t slot = out_base + wa.ray_base + __popcll(m_refl & below);
+            p.q_org[qo][slot] = make_float4(over_point.x, over_point.y, over_point.z, over_point.w);
+            p.q_dir[qo][slot] = make_float4(reflectv.x, reflectv.y, reflectv.z, reflectv.w);
+            p.q_link[qo][slot] = make_uint2(node, __float_as_uint(reflective));
         }
-        const uint32_t t_slot = wave_alloc(&p.counters->queue_count[level + 1], spawn_refract);
         if (spawn_refract) {
-            p.q_org[qo][t_slot] = make_float4(under_point.x, under_point.y, under_point.z, under_point.w);
-            p.q_dir[qo][t_slot] = make_float4(refract_dir.x, refract_dir.y, refract_dir.z, refract_dir.w);
-            p.q_link[qo][t_slot] = make_uint2(node | kLinkSlotBit, __float_as_uint(transparency));
+            const uint32_t slot = out_base + wa.ray_base + n_refl + __popcll(m_refr & below);
+            p.q_org[qo][slot] = make_float4(under_point.x, under_point.y, under_point.z, under_point.w);
+            p.q_dir[qo][slot] = make_float4(refract_dir.x, refract_dir.y, refract_dir.z, refract_dir.w);
+            p.q_link[qo][slot] = make_uint2(node | kLinkSlotBit, __float_as_uint(transparency));
         }
     }
     // one atomic per wave for the hit (= shadow ray) count
-    for (int off = 32; off > 0; off >>= 1) local_hits += __shfl_down(local_hits, off);
-    if (lane == 0 && local_hits) atomicAdd(&p.counters->hits[level], local_hits);
+    for (int off = 32; off > 0; off >>= 1) {
+        local_hits += __shfl_down(local_hits, off);
+        local_patterned += __shfl_down(local_patterned, off);
+        local_transparent += __shfl_down(local_transparent, off);
+    }
+    if (lane == 0 && local_hits) {
+        atomicAdd(&p.counters->hits[level], local_hits);
+        if (local_patterned) atomicAdd(&p.counters->hits_patterned, local_patterned);
+        if (local_transparent) atomicAdd(&p.counters->hits_transparent, local_transparent);
+    }
 }
 
 // Interior nodes of one level, after every deeper level has delivered into their slots.
 __global__ __launch_bounds__(256) void k_combine(const Params p, const uint32_t level) {
-    const uint32_t count = p.counters->node_count[level];
     const bool root = level == 0;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
-        const uint32_t node = p.node_off[level] + i;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t shard = wave % kShards;
+    const uint32_t count = static_cast<uint32_t>(p.counters->shard[shard].alloc[level] >> 32);
+    const uint32_t node_base = p.node_off[level] + shard * (p.shard_cap0 << level);
+    for (uint32_t i = (wave / kShards) * 64u + lane; i < count; i += (n_waves / kShards) * 64u) {
+        const uint32_t node = node_base + i;
         const float4 a = p.node_a[node], b = p.node_b[node], c = p.node_c[node];
         const uint32_t bits = __float_as_uint(c.w);
         const Color out = combine(Color{a.x, a.y, a.z}, Color{b.x, b.y, b.z}, Color{c.x, c.y, c.z},
@@ -776,16 +843,20 @@ __global__ __launch_bounds__(256) void k_combine(const Params p, const uint32_t 
 __global__ void k_accumulate(Counters* c, Totals* t, uint32_t level0_rays, uint32_t depth) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     t->level_rays[0] += level0_rays;
-    for (uint32_t l = 1; l <= depth; ++l) t->level_rays[l] += c->queue_count[l];
-    for (uint32_t l = 0; l <= depth; ++l) {
-        t->hits += c->hits[l];
-        t->nodes += c->node_count[l];
+    for (uint32_t k = 0; k < kShards; ++k) {
+        for (uint32_t l = 0; l <= depth; ++l) {
+            const unsigned long long a = c->shard[k].alloc[l];
+            if (l + 1 <= depth) t->level_rays[l + 1] += static_cast<uint32_t>(a);
+            t->nodes += a >> 32;
+            c->shard[k].alloc[l] = 0ull;
+        }
     }
-    for (int l = 0; l <= kLevels; ++l) c->queue_count[l] = 0;
-    for (int l = 0; l < kLevels; ++l) {
-        c->node_count[l] = 0;
-        c->hits[l] = 0;
-    }
+    for (uint32_t l = 0; l <= depth; ++l) t->level_hits[l] += c->hits[l];
+    t->hits_patterned += c->hits_patterned;
+    t->hits_transparent += c->hits_transparent;
+    c->hits_patterned = 0;
+    c->hits_transparent = 0;
+    for (int l = 0; l < kLevels; ++l) c->hits[l] = 0;
 }
 
 // canvas.zig:45-47: round(clamp(c * 255, 0, 255)), round half away from zero.
@@ -815,6 +886,7 @@ struct rtx_scene {
 
     // work buffers, sized for `cap_pixels` pixels per batch at depth kMaxDepth
     uint32_t cap_pixels = 0;
+    uint32_t shard_cap0 = 0;  // level-0 items per shard the buffers were sized for
     float4* q_org[2] = {nullptr, nullptr};
     float4* q_dir[2] = {nullptr, nullptr};
     uint2* q_link[2] = {nullptr, nullptr};
@@ -827,6 +899,10 @@ struct rtx_scene {
     size_t canvas_floats = 0;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     int num_cus = 256;
+    // profile = 1: pooled events bracketing each launch, pending until read back
+    std::vector<hipEvent_t> prof_events;
+    std::vector<int> prof_kind;  // per pair: 0 trace_shade, 1 combine
+    size_t prof_used = 0;
 };
 
 namespace {
@@ -851,9 +927,14 @@ void free_work(rtx_scene* s) {
 int ensure_work(rtx_scene* s, uint32_t pixels) {
     if (pixels <= s->cap_pixels) return RTX_OK;
     free_work(s);
-    const size_t q_cap = (size_t)pixels << kMaxDepth;  // largest level
+    // Level-0 chunks of 64 items are dealt round-robin to the shards, so a shard sees at most
+    // 64 * ceil(chunks / kShards) items at level 0 and 2^d times that at level d.
+    const uint32_t chunks = (pixels + 63u) / 64u;
+    const uint32_t shard_cap0 = 64u * ((chunks + kShards - 1u) / kShards);
+    const size_t per_level0 = (size_t)kShards * shard_cap0;
+    const size_t q_cap = per_level0 << kMaxDepth;  // largest level
     size_t node_cap = 0;
-    for (int l = 0; l < kMaxDepth; ++l) node_cap += (size_t)pixels << l;
+    for (int l = 0; l < kMaxDepth; ++l) node_cap += per_level0 << l;
     for (int i = 0; i < 2; ++i) {
         HIP_TRY(hipMalloc(&s->q_org[i], q_cap * sizeof(float4)));
         HIP_TRY(hipMalloc(&s->q_dir[i], q_cap * sizeof(float4)));
@@ -863,6 +944,7 @@ int ensure_work(rtx_scene* s, uint32_t pixels) {
     HIP_TRY(hipMalloc(&s->node_b, node_cap * sizeof(float4)));
     HIP_TRY(hipMalloc(&s->node_c, node_cap * sizeof(float4)));
     s->cap_pixels = pixels;
+    s->shard_cap0 = shard_cap0;
     return RTX_OK;
 }
 
@@ -973,47 +1055,65 @@ void fill_scene_params(const rtx_scene* s, Params& p, uint32_t depth) {
     p.counters = s->d_counters;
 }
 
-struct ProfileEvents {
-    std::vector<hipEvent_t> ev;
-    std::vector<int> kind;  // 0 trace_shade, 1 combine
-    ~ProfileEvents() {
-        for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+// Sum the pending profile events into `out` and mark them consumed (stream must be idle).
+int collect_profile(rtx_scene* s, rtx_stats* out) {
+    for (size_t i = 0; i + 1 < s->prof_used; i += 2) {
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, s->prof_events[i], s->prof_events[i + 1]));
+        if (s->prof_kind[i / 2] == 0) {
+            out->ms_trace_shade += ms;
+            out->launches_trace_shade++;
+        } else {
+            out->ms_combine += ms;
+            out->launches_combine++;
+        }
     }
-};
+    s->prof_used = 0;
+    s->prof_kind.clear();
+    return RTX_OK;
+}
 
 // Run the levels for one batch whose level-0 rays are either generated (GEN) or already in
 // queue 0 (rtx_color_at).
 template <bool GEN>
-int run_levels(rtx_scene* s, Params& p, uint32_t pixels, uint32_t level0_items, hipStream_t st, ProfileEvents* prof) {
+int run_levels(rtx_scene* s, Params& p, uint32_t pixels, uint32_t level0_items, hipStream_t st, bool prof) {
+    p.shard_cap0 = s->shard_cap0;
     uint32_t off = 0;
     for (int l = 0; l < kLevels; ++l) {
         p.node_off[l] = off;
-        if (l < kMaxDepth) off += pixels << l;
+        if (l < kMaxDepth) off += (kShards * s->shard_cap0) << l;
     }
-    const uint32_t max_blocks = (uint32_t)s->num_cus * 8u;
+    // Every launch has a multiple of kShards waves (16 blocks of 4 waves), see k_trace_shade.
+    constexpr uint32_t kBlockQuantum = kShards / 4u;
+    uint32_t max_blocks = ((uint32_t)s->num_cus * 8u) / kBlockQuantum * kBlockQuantum;
+    if (max_blocks < kBlockQuantum) max_blocks = kBlockQuantum;
+    auto grid_for = [&](uint64_t items) {
+        uint64_t blocks = (items + 255) / 256;
+        blocks = (blocks + kBlockQuantum - 1) / kBlockQuantum * kBlockQuantum;
+        if (blocks > max_blocks) blocks = max_blocks;
+        if (blocks < kBlockQuantum) blocks = kBlockQuantum;
+        return (uint32_t)blocks;
+    };
     auto mark = [&](int kind) {
         if (!prof) return;
-        hipEvent_t e;
-        (void)hipEventCreate(&e);
-        (void)hipEventRecord(e, st);
-        prof->ev.push_back(e);
-        prof->kind.push_back(kind);
+        if (s->prof_used == s->prof_events.size()) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return;
+            s->prof_events.push_back(e);
+        }
+        (void)hipEventRecord(s->prof_events[s->prof_used++], st);
+        if (kind >= 0) s->prof_kind.push_back(kind);
     };
     for (uint32_t level = 0; level <= p.depth; ++level) {
         // Level 0 knows its size; deeper levels read theirs on the device and grid-stride.
-        uint64_t items = level == 0 ? level0_items : ((uint64_t)pixels << level);
-        uint32_t blocks = (uint32_t)((items + 255) / 256);
-        if (blocks > max_blocks) blocks = max_blocks;
-        if (blocks == 0) blocks = 1;
+        const uint32_t blocks = grid_for(level == 0 ? level0_items : ((uint64_t)pixels << level));
         mark(0);
         if (level == 0) launch_trace<GEN>(s, p, level, blocks, st);
         else launch_trace<false>(s, p, level, blocks, st);
         mark(-1);
     }
     for (int level = (int)p.depth - 1; level >= 0; --level) {
-        uint64_t items = (uint64_t)pixels << level;
-        uint32_t blocks = (uint32_t)((items + 255) / 256);
-        if (blocks > max_blocks) blocks = max_blocks;
+        const uint32_t blocks = grid_for((uint64_t)pixels << level);
         mark(1);
         hipLaunchKernelGGL(k_combine, dim3(blocks), dim3(256), 0, st, p, (uint32_t)level);
         mark(-1);
@@ -1071,13 +1171,12 @@ int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_opts* opts, float
     HIP_TRY(hipMemsetAsync(s->d_counters, 0, sizeof(Counters), st));
     HIP_TRY(hipMemsetAsync(s->d_totals, 0, sizeof(Totals), st));
 
-    ProfileEvents prof;
     for (uint32_t row0 = 0; row0 < plan.rows_local; row0 += rows_per_batch) {
         const uint32_t n_rows = (plan.rows_local - row0 < rows_per_batch) ? plan.rows_local - row0 : rows_per_batch;
         p.row0 = row0;
         p.n_rows = n_rows;
         const uint32_t items = tiles_x * ((n_rows + 7u) / 8u) * 64u;
-        rc = run_levels<true>(s, p, cap, items, st, profile ? &prof : nullptr);
+        rc = run_levels<true>(s, p, cap, items, st, profile);
         if (rc) return rc;
     }
     if (d_rgb8) {
@@ -1099,22 +1198,18 @@ int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_opts* opts, float
             stats->level_rays[l] = t.level_rays[l];
             stats->rays_secondary += t.level_rays[l];
         }
-        stats->rays_shadow = t.hits;
+        for (uint32_t l = 0; l <= depth; ++l) {
+            stats->level_hits[l] = t.level_hits[l];
+            stats->rays_shadow += t.level_hits[l];
+        }
         stats->nodes = t.nodes;
+        stats->hits_patterned = t.hits_patterned;
+        stats->hits_transparent = t.hits_transparent;
         stats->rows_rendered = plan.rows_local;
         HIP_TRY(hipEventElapsedTime(&stats->ms_total, s->ev_begin, s->ev_end));
         if (profile) {
-            for (size_t i = 0; i + 1 < prof.ev.size(); i += 2) {
-                float ms = 0.0f;
-                HIP_TRY(hipEventElapsedTime(&ms, prof.ev[i], prof.ev[i + 1]));
-                if (prof.kind[i] == 0) {
-                    stats->ms_trace_shade += ms;
-                    stats->launches_trace_shade++;
-                } else {
-                    stats->ms_combine += ms;
-                    stats->launches_combine++;
-                }
-            }
+            rc = collect_profile(s, stats);
+            if (rc) return rc;
         }
     }
     return RTX_OK;
@@ -1200,10 +1295,20 @@ void rtx_scene_destroy(rtx_scene* s) {
     if (s->d_patterns) (void)hipFree(s->d_patterns);
     if (s->d_counters) (void)hipFree(s->d_counters);
     if (s->d_totals) (void)hipFree(s->d_totals);
+    for (hipEvent_t e : s->prof_events) (void)hipEventDestroy(e);
     if (s->ev_begin) (void)hipEventDestroy(s->ev_begin);
     if (s->ev_end) (void)hipEventDestroy(s->ev_end);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
+}
+
+int rtx_profile_collect(rtx_scene* s, rtx_stats* out) {
+    if (!s || !out) return fail(RTX_E_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(s->device));
+    // Events may sit on a caller's stream: wait for the whole device.
+    HIP_TRY(hipDeviceSynchronize());
+    std::memset(out, 0, sizeof *out);
+    return collect_profile(s, out);
 }
 
 int rtx_rows_for(const rtx_camera* cam, const rtx_opts* opts, uint32_t* n_rows) {
@@ -1266,7 +1371,7 @@ int rtx_color_at(rtx_scene* s, const float* origins, const float* directions, ui
     fill_scene_params(s, p, depth);
     p.canvas = s->d_canvas;
     p.root_count = n;
-    rc = run_levels<false>(s, p, n, n, st, nullptr);
+    rc = run_levels<false>(s, p, n, n, st, false);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(rgb_out, s->d_canvas, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));

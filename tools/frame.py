@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Render one sample scene a few times on cuda:0 (profiling driver for rocprofv3).
+
+    python tools/frame.py <sample> <W> <H> [frames] [batch_pixels]
+"""
+import importlib
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+rta = importlib.import_module("ray-tracer_amd")
+
+name = sys.argv[1] if len(sys.argv) > 1 else "glass_spheres"
+w = int(sys.argv[2]) if len(sys.argv) > 2 else 1920
+h = int(sys.argv[3]) if len(sys.argv) > 3 else 1080
+frames = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+batch = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+s = rta.Sample(name, w, h)
+scene = rta.Scene(s.world)
+for i in range(frames):
+    canvas, st = scene.render(s.camera, batch_pixels=batch, profile=True)
+print(name, w, h, "rays", st.rays_primary, st.rays_shadow, st.rays_secondary, "levels", list(st.level_rays),
+      "hits", list(st.level_hits), "ms_total %.3f trace %.3f (%d launches) combine %.3f" % (
+          st.ms_total, st.ms_trace_shade, st.launches_trace_shade, st.ms_combine))
+scene.close()
