@@ -27,6 +27,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -89,15 +90,14 @@ constexpr uint32_t kShards = 64;
 struct ShardCounters {  // one 128-byte line per shard
     // per level d: low 32 bits = rays queued for level d + 1, high 32 bits = interior nodes at d
     unsigned long long alloc[kLevels];
-    unsigned long long pad[16 - kLevels];
+    unsigned long long hit_kinds;  // low 32: hits on patterned materials, high 32: on transparent ones
+    uint32_t hits[kLevels];        // hits at level d == isShadowed calls
+    uint32_t pad[32 - 2 * kLevels - 2 - kLevels];
 };
+static_assert(sizeof(ShardCounters) == 128, "one cache line per shard");
 
 struct Counters {
     ShardCounters shard[kShards];
-    uint32_t hits[kLevels];             // hits at level d == isShadowed calls
-    uint32_t hits_patterned;
-    uint32_t hits_transparent;
-    uint32_t pad;
 };
 
 struct Totals {
@@ -115,6 +115,9 @@ struct Params {
     const rtx_pattern* patterns;
     uint32_t n_nodes;
     uint32_t n_shapes;
+    uint32_t n_materials;
+    uint32_t n_patterns;
+    uint32_t lds_bytes;  // > 0: the scene tables are staged in this much dynamic LDS
     uint32_t track_n1;  // scene has a transparent material: track the n1 predecessor
     uint32_t depth;
     float light_position[4];
@@ -543,10 +546,10 @@ __device__ __forceinline__ Color pattern_at_shape(const rtx_pattern& pat, const 
 }
 
 // Material.lighting (src/material.zig:40-102)
-__device__ __forceinline__ Color lighting(const Params& p, const rtx_material& m, const rtx_shape& sh, V4 point, V4 eye,
-                                          V4 normal, bool in_shadow) {
+__device__ __forceinline__ Color lighting(const Params& p, const rtx_pattern* patterns, const rtx_material& m,
+                                          const rtx_shape& sh, V4 point, V4 eye, V4 normal, bool in_shadow) {
     Color color;
-    if (m.pattern >= 0) color = pattern_at_shape(p.patterns[m.pattern], sh, point);
+    if (m.pattern >= 0) color = pattern_at_shape(patterns[m.pattern], sh, point);
     else color = Color{m.color[0], m.color[1], m.color[2]};
 
     const Color li{p.light_intensity[0], p.light_intensity[1], p.light_intensity[2]};
@@ -635,10 +638,72 @@ __device__ __forceinline__ void deliver(const Params& p, bool root, uint32_t lin
 
 // ------------------------------------------------------------------------ kernels
 
+// Diagnostic build only (-DRTX_DIAG, `make diag`): per-phase cycle shares of k_trace_shade,
+// every phase fenced with a full s_waitcnt so a wait is charged to the phase that issued the
+// memory operation.  Never compiled into the product library; timings of this build are
+// meaningless, only the shares are read (tools/diag_phases.py).
+#ifdef RTX_DIAG
+__device__ unsigned long long g_diag[16];
+#define DIAG_DECL unsigned long long diag_t = 0, diag_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define DIAG_START()                                                     \
+    do {                                                                 \
+        __builtin_amdgcn_s_waitcnt(0);                                   \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      \
+        diag_t = __builtin_readcyclecounter();                           \
+    } while (0)
+#define DIAG_PHASE(k)                                                    \
+    do {                                                                 \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      \
+        const unsigned long long now_ = __builtin_readcyclecounter();    \
+        diag_acc[k] += now_ - diag_t;                                    \
+        diag_t = now_;                                                   \
+    } while (0)
+#define DIAG_FLUSH()                                                     \
+    do {                                                                 \
+        if ((threadIdx.x & 63u) == 0u)                                   \
+            for (int k_ = 0; k_ < 8; ++k_) atomicAdd(&g_diag[k_], diag_acc[k_]); \
+    } while (0)
+#else
+#define DIAG_DECL
+#define DIAG_START()
+#define DIAG_PHASE(k)
+#define DIAG_FLUSH()
+#endif
+
+// Scene tables staged in LDS (CDNA4: 160 KB per CU).  The hit shape, its material and its
+// pattern are per-lane lookups (normalAt, lighting, n1/n2); from global memory each is a
+// dependent L2 round trip per lane and the diagnostic build showed 65 % of the kernel waiting
+// on them, so scenes whose tables fit kLdsSceneBytes are copied into LDS once per block.
+constexpr uint32_t kLdsSceneBytes = 32768;  // 4 blocks per CU keep 128 KB of the 160 KB
+
+struct LdsScene {
+    const rtx_shape* shapes;
+    const rtx_material* materials;
+    const rtx_pattern* patterns;
+};
+
 // One ray-tree level.  GEN: level-0 rays come from the camera (rayForPixel,
-// src/camera.zig:70-82) instead of the queue.  TRACK: keep the n1 predecessor.
-template <bool GEN, bool TRACK>
+// src/camera.zig:70-82) instead of the queue.  TRACK: keep the n1 predecessor.  LDS: the
+// scene tables fit in LDS (p.lds_bytes of dynamic shared memory).
+template <bool GEN, bool TRACK, bool LDS>
 __global__ __launch_bounds__(256) void k_trace_shade(const Params p, const uint32_t level) {
+    extern __shared__ uint4 lds_raw[];
+    LdsScene tab{p.shapes, p.materials, p.patterns};
+    if (LDS) {
+        // [shapes][materials][patterns], all record sizes are multiples of 16 bytes.
+        const uint32_t n_sh = p.n_shapes * (uint32_t)(sizeof(rtx_shape) / 16), n_ma = p.n_materials * (uint32_t)(sizeof(rtx_material) / 16),
+                       n_pa = p.n_patterns * (uint32_t)(sizeof(rtx_pattern) / 16);
+        const uint4* g_sh = reinterpret_cast<const uint4*>(p.shapes);
+        const uint4* g_ma = reinterpret_cast<const uint4*>(p.materials);
+        const uint4* g_pa = reinterpret_cast<const uint4*>(p.patterns);
+        for (uint32_t k = threadIdx.x; k < n_sh; k += blockDim.x) lds_raw[k] = g_sh[k];
+        for (uint32_t k = threadIdx.x; k < n_ma; k += blockDim.x) lds_raw[n_sh + k] = g_ma[k];
+        for (uint32_t k = threadIdx.x; k < n_pa; k += blockDim.x) lds_raw[n_sh + n_ma + k] = g_pa[k];
+        __syncthreads();
+        tab.shapes = reinterpret_cast<const rtx_shape*>(lds_raw);
+        tab.materials = reinterpret_cast<const rtx_material*>(lds_raw + n_sh);
+        tab.patterns = reinterpret_cast<const rtx_pattern*>(lds_raw + n_sh + n_ma);
+    }
     const bool root = level == 0;
     const uint32_t remaining = p.depth - level;  // `remaining` of colorAtInternal (src/world.zig:85)
     const uint32_t qi = level & 1u, qo = qi ^ 1u;
@@ -666,7 +731,9 @@ __global__ __launch_bounds__(256) void k_trace_shade(const Params p, const uint3
     const uint32_t node_base = p.node_off[level] + shard * (p.shard_cap0 << level);
 
     uint32_t local_hits = 0, local_patterned = 0, local_transparent = 0;
+    DIAG_DECL
     for (uint32_t base = first; base < count; base += stride) {
+        DIAG_START();
         const uint32_t i = base + lane;
         bool on = i < count;
         V4 o, d;
@@ -705,11 +772,13 @@ __global__ __launch_bounds__(256) void k_trace_shade(const Params p, const uint3
             d = v4(0.0f, 0.0f, 1.0f, 0.0f);
         }
 
+        DIAG_PHASE(0);  // ray fetch / generation
         // colorAtInternal: world.intersect + hit (src/world.zig:85-95)
         ClosestVisitor<TRACK> cv;
         cv.init();
         traverse(cv, p, o, d, on);
         const bool is_hit = on && cv.c.idx != kNone;
+        DIAG_PHASE(1);  // closest-hit traversal
 
         // prepareComputations (src/intersection.zig:43-90) and the shadow ray
         // (src/world.zig:55,97-106), per lane.
@@ -717,13 +786,13 @@ __global__ __launch_bounds__(256) void k_trace_shade(const Params p, const uint3
         float n1 = 1.0f, n2 = 1.0f, shadow_distance = 0.0f;
         if (is_hit) {
             ++local_hits;
-            const rtx_shape& sh = p.shapes[cv.c.idx];
+            const rtx_shape& sh = tab.shapes[cv.c.idx];
             point = add(o, muls(d, cv.c.t));  // ray.position, src/ray.zig:9-11
             normal = normal_at(sh, point);
             if (dot(normal, neg(d)) < 0.0f) normal = neg(normal);
             // n1 / n2 (src/intersection.zig:92-159, see Closest above)
-            if (TRACK && cv.c.pred_idx != kNone) n1 = p.materials[p.shapes[cv.c.pred_idx].material].refractive_index;
-            n2 = p.materials[sh.material].refractive_index;
+            if (TRACK && cv.c.pred_idx != kNone) n1 = tab.materials[tab.shapes[cv.c.pred_idx].material].refractive_index;
+            n2 = tab.materials[sh.material].refractive_index;
             over_point = add(point, muls(normal, p.over_eps));
             const V4 lp = v4(p.light_position[0], p.light_position[1], p.light_position[2], p.light_position[3]);
             const V4 to_light = sub(lp, over_point);
@@ -731,20 +800,22 @@ __global__ __launch_bounds__(256) void k_trace_shade(const Params p, const uint3
             shadow_dir = normalize(to_light);
         }
 
+        DIAG_PHASE(2);  // prepareComputations + shadow-ray set-up
         // isShadowed (src/world.zig:97-120).  The traversal loop is wave-uniform, so it runs
         // outside the divergent branch; lanes without a hit are parked.
         ShadowVisitor sv;
         sv.distance = shadow_distance;
         sv.found = false;
         traverse(sv, p, over_point, shadow_dir, is_hit);
+        DIAG_PHASE(3);  // shadow traversal
 
         bool spawn_reflect = false, spawn_refract = false, use_schlick = false;
         float reflectance = 0.0f, reflective = 0.0f, transparency = 0.0f;
         Color surface{0.0f, 0.0f, 0.0f};
         V4 reflectv = d, under_point = o, refract_dir = d;
         if (is_hit) {
-            const rtx_shape& sh = p.shapes[cv.c.idx];
-            const rtx_material& m = p.materials[sh.material];
+            const rtx_shape& sh = tab.shapes[cv.c.idx];
+            const rtx_material& m = tab.materials[sh.material];
             const V4 eye = neg(d);
             reflectv = reflect(d, normal);
             reflective = m.reflective;
@@ -752,7 +823,7 @@ __global__ __launch_bounds__(256) void k_trace_shade(const Params p, const uint3
             local_patterned += m.pattern >= 0 ? 1u : 0u;
             local_transparent += m.transparency != 0.0f ? 1u : 0u;
             // shadeHitInternal (src/world.zig:54-79): Phong is evaluated at over_point.
-            surface = lighting(p, m, sh, over_point, eye, normal, sv.found);
+            surface = lighting(p, tab.patterns, m, sh, over_point, eye, normal, sv.found);
             // reflectedColorInternal (src/world.zig:126-143)
             spawn_reflect = remaining != 0u && m.reflective != 0.0f;
             // refractedColorInternal (src/world.zig:149-186)
@@ -773,6 +844,7 @@ __global__ __launch_bounds__(256) void k_trace_shade(const Params p, const uint3
             }
         }
 
+        DIAG_PHASE(4);  // lighting, refraction set-up, Schlick
         // Leaves finish here; interior nodes park their surface colour for k_combine.
         const bool interior = spawn_reflect || spawn_refract;
         if (on && !interior) {
@@ -785,7 +857,9 @@ __global__ __launch_bounds__(256) void k_trace_shade(const Params p, const uint3
         const unsigned long long m_node = __ballot(interior), m_refl = __ballot(spawn_reflect), m_refr = __ballot(spawn_refract);
         const unsigned long long below = (1ull << lane) - 1ull;
         const uint32_t n_refl = __popcll(m_refl);
+        DIAG_PHASE(5);  // leaf delivery
         const WaveAlloc wa = wave_alloc(&sc->alloc[level], n_refl + __popcll(m_refr), __popcll(m_node));
+        DIAG_PHASE(6);  // slot allocation (the atomic)
         uint32_t node = 0;
         if (interior) {
             node = node_base + wa.node_base + __popcll(m_node & below);
@@ -806,17 +880,21 @@ __global__ __launch_bounds__(256) void k_trace_shade(const Params p, const uint3
             p.q_dir[qo][slot] = make_float4(refract_dir.x, refract_dir.y, refract_dir.z, refract_dir.w);
             p.q_link[qo][slot] = make_uint2(node | kLinkSlotBit, __float_as_uint(transparency));
         }
+        DIAG_PHASE(7);  // node + child-ray stores
     }
+    DIAG_FLUSH();
     // one atomic per wave for the hit (= shadow ray) count
     for (int off = 32; off > 0; off >>= 1) {
         local_hits += __shfl_down(local_hits, off);
         local_patterned += __shfl_down(local_patterned, off);
         local_transparent += __shfl_down(local_transparent, off);
     }
+    // Statistics go to the wave's shard line too: a chip-wide counter word would serialise
+    // every wave of the launch at the memory side (measured: ~11 ns per same-address atomic).
     if (lane == 0 && local_hits) {
-        atomicAdd(&p.counters->hits[level], local_hits);
-        if (local_patterned) atomicAdd(&p.counters->hits_patterned, local_patterned);
-        if (local_transparent) atomicAdd(&p.counters->hits_transparent, local_transparent);
+        atomicAdd(&sc->hits[level], local_hits);
+        if (local_patterned | local_transparent)
+            atomicAdd(&sc->hit_kinds, (static_cast<unsigned long long>(local_transparent) << 32) | local_patterned);
     }
 }
 
@@ -849,14 +927,14 @@ __global__ void k_accumulate(Counters* c, Totals* t, uint32_t level0_rays, uint3
             if (l + 1 <= depth) t->level_rays[l + 1] += static_cast<uint32_t>(a);
             t->nodes += a >> 32;
             c->shard[k].alloc[l] = 0ull;
+            t->level_hits[l] += c->shard[k].hits[l];
+            c->shard[k].hits[l] = 0u;
         }
+        t->hits_patterned += static_cast<uint32_t>(c->shard[k].hit_kinds);
+        t->hits_transparent += c->shard[k].hit_kinds >> 32;
+        c->shard[k].hit_kinds = 0ull;
     }
-    for (uint32_t l = 0; l <= depth; ++l) t->level_hits[l] += c->hits[l];
-    t->hits_patterned += c->hits_patterned;
-    t->hits_transparent += c->hits_transparent;
-    c->hits_patterned = 0;
-    c->hits_transparent = 0;
-    for (int l = 0; l < kLevels; ++l) c->hits[l] = 0;
+
 }
 
 // canvas.zig:45-47: round(clamp(c * 255, 0, 255)), round half away from zero.
@@ -987,10 +1065,16 @@ RowPlan plan_rows(const rtx_camera* cam, const rtx_opts* o) {
     return r;
 }
 
+template <bool GEN, bool TRACK>
+void launch_trace2(const Params& p, uint32_t level, uint32_t blocks, hipStream_t st) {
+    if (p.lds_bytes) hipLaunchKernelGGL((k_trace_shade<GEN, TRACK, true>), dim3(blocks), dim3(256), p.lds_bytes, st, p, level);
+    else hipLaunchKernelGGL((k_trace_shade<GEN, TRACK, false>), dim3(blocks), dim3(256), 0, st, p, level);
+}
+
 template <bool GEN>
 void launch_trace(const rtx_scene* s, const Params& p, uint32_t level, uint32_t blocks, hipStream_t st) {
-    if (s->track_n1) hipLaunchKernelGGL((k_trace_shade<GEN, true>), dim3(blocks), dim3(256), 0, st, p, level);
-    else hipLaunchKernelGGL((k_trace_shade<GEN, false>), dim3(blocks), dim3(256), 0, st, p, level);
+    if (s->track_n1) launch_trace2<GEN, true>(p, level, blocks, st);
+    else launch_trace2<GEN, false>(p, level, blocks, st);
 }
 
 int validate_desc(const rtx_scene_desc* d) {
@@ -1039,6 +1123,13 @@ void fill_scene_params(const rtx_scene* s, Params& p, uint32_t depth) {
     p.patterns = s->d_patterns;
     p.n_nodes = s->n_nodes;
     p.n_shapes = s->n_shapes;
+    p.n_materials = s->n_materials;
+    p.n_patterns = s->n_patterns;
+    {
+        const size_t bytes = sizeof(rtx_shape) * s->n_shapes + sizeof(rtx_material) * s->n_materials +
+                             sizeof(rtx_pattern) * s->n_patterns;
+        p.lds_bytes = bytes <= kLdsSceneBytes ? (uint32_t)bytes : 0u;
+    }
     p.track_n1 = s->track_n1 ? 1u : 0u;
     p.depth = depth;
     std::memcpy(p.light_position, s->light_position, sizeof p.light_position);
@@ -1085,7 +1176,12 @@ int run_levels(rtx_scene* s, Params& p, uint32_t pixels, uint32_t level0_items, 
     }
     // Every launch has a multiple of kShards waves (16 blocks of 4 waves), see k_trace_shade.
     constexpr uint32_t kBlockQuantum = kShards / 4u;
-    uint32_t max_blocks = ((uint32_t)s->num_cus * 8u) / kBlockQuantum * kBlockQuantum;
+    static const uint32_t blocks_per_cu = [] {  // tuning knob for experiments; default 4 = one resident round
+        const char* e = getenv("RTX_BLOCKS_PER_CU");
+        const int v = e ? atoi(e) : 0;
+        return (uint32_t)(v > 0 ? v : 4);
+    }();
+    uint32_t max_blocks = ((uint32_t)s->num_cus * blocks_per_cu) / kBlockQuantum * kBlockQuantum;
     if (max_blocks < kBlockQuantum) max_blocks = kBlockQuantum;
     auto grid_for = [&](uint64_t items) {
         uint64_t blocks = (items + 255) / 256;
@@ -1140,7 +1236,7 @@ int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_opts* opts, float
     const size_t out_rows = compact ? plan.rows_local : H;
 
     // Batch: whole 8-row bands, at most batch_pixels pixels.
-    uint32_t batch_pixels = (opts && opts->batch_pixels) ? opts->batch_pixels : (1u << 20);
+    uint32_t batch_pixels = (opts && opts->batch_pixels) ? opts->batch_pixels : (1u << 21);
     if (batch_pixels > (1u << 22)) batch_pixels = 1u << 22;  // keeps (pixels << depth) inside 30 bits
     uint32_t rows_per_batch = (batch_pixels / W) & ~7u;
     if (rows_per_batch < 8) rows_per_batch = 8;
@@ -1216,6 +1312,18 @@ int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_opts* opts, float
 }
 
 }  // namespace
+
+#ifdef RTX_DIAG
+extern "C" __attribute__((visibility("default"))) int rtx_diag_read(unsigned long long* out16, int reset) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_diag), sizeof(unsigned long long) * 16));
+    if (reset) {
+        unsigned long long z[16] = {0};
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_diag), z, sizeof z));
+    }
+    return 0;
+}
+#endif
 
 extern "C" {
 
