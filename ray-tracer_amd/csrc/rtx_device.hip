@@ -917,24 +917,43 @@ __global__ __launch_bounds__(256) void k_combine(const Params p, const uint32_t 
     }
 }
 
-// Fold this batch's counters into the running totals and clear them for the next batch.
-__global__ void k_accumulate(Counters* c, Totals* t, uint32_t level0_rays, uint32_t depth) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    t->level_rays[0] += level0_rays;
-    for (uint32_t k = 0; k < kShards; ++k) {
-        for (uint32_t l = 0; l <= depth; ++l) {
-            const unsigned long long a = c->shard[k].alloc[l];
-            if (l + 1 <= depth) t->level_rays[l + 1] += static_cast<uint32_t>(a);
-            t->nodes += a >> 32;
-            c->shard[k].alloc[l] = 0ull;
-            t->level_hits[l] += c->shard[k].hits[l];
-            c->shard[k].hits[l] = 0u;
-        }
-        t->hits_patterned += static_cast<uint32_t>(c->shard[k].hit_kinds);
-        t->hits_transparent += c->shard[k].hit_kinds >> 32;
-        c->shard[k].hit_kinds = 0ull;
+// Fold this batch's counters into the running totals and clear them for the next batch:
+// one wave, lane k owns shard k.  `reset` starts a new frame's totals.
+__global__ void k_accumulate(Counters* c, Totals* t, uint32_t level0_rays, uint32_t depth, uint32_t reset) {
+    const uint32_t k = threadIdx.x;  // blockDim.x == kShards == 64
+    ShardCounters* sc = &c->shard[k];
+    unsigned long long rays[kLevels], hits[kLevels], nodes = 0, patterned, transparent;
+#pragma unroll
+    for (int l = 0; l < kLevels; ++l) {
+        const unsigned long long a = sc->alloc[l];
+        rays[l] = (static_cast<uint32_t>(l) <= depth) ? static_cast<uint32_t>(a) : 0u;
+        nodes += (static_cast<uint32_t>(l) <= depth) ? (a >> 32) : 0ull;
+        hits[l] = sc->hits[l];
+        sc->alloc[l] = 0ull;
+        sc->hits[l] = 0u;
     }
-
+    patterned = static_cast<uint32_t>(sc->hit_kinds);
+    transparent = sc->hit_kinds >> 32;
+    sc->hit_kinds = 0ull;
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int l = 0; l < kLevels; ++l) {
+            rays[l] += __shfl_down(rays[l], off);
+            hits[l] += __shfl_down(hits[l], off);
+        }
+        nodes += __shfl_down(nodes, off);
+        patterned += __shfl_down(patterned, off);
+        transparent += __shfl_down(transparent, off);
+    }
+    if (k == 0) {
+        if (reset) *t = Totals{};
+        t->level_rays[0] += level0_rays;
+        for (uint32_t l = 0; l < depth; ++l) t->level_rays[l + 1] += rays[l];
+        for (uint32_t l = 0; l <= depth; ++l) t->level_hits[l] += hits[l];
+        t->nodes += nodes;
+        t->hits_patterned += patterned;
+        t->hits_transparent += transparent;
+    }
 }
 
 // canvas.zig:45-47: round(clamp(c * 255, 0, 255)), round half away from zero.
@@ -1167,7 +1186,7 @@ int collect_profile(rtx_scene* s, rtx_stats* out) {
 // Run the levels for one batch whose level-0 rays are either generated (GEN) or already in
 // queue 0 (rtx_color_at).
 template <bool GEN>
-int run_levels(rtx_scene* s, Params& p, uint32_t pixels, uint32_t level0_items, hipStream_t st, bool prof) {
+int run_levels(rtx_scene* s, Params& p, uint32_t pixels, uint32_t level0_items, hipStream_t st, bool prof, bool first) {
     p.shard_cap0 = s->shard_cap0;
     uint32_t off = 0;
     for (int l = 0; l < kLevels; ++l) {
@@ -1214,7 +1233,8 @@ int run_levels(rtx_scene* s, Params& p, uint32_t pixels, uint32_t level0_items, 
         hipLaunchKernelGGL(k_combine, dim3(blocks), dim3(256), 0, st, p, (uint32_t)level);
         mark(-1);
     }
-    hipLaunchKernelGGL(k_accumulate, dim3(1), dim3(64), 0, st, s->d_counters, s->d_totals, level0_items ? pixels : 0u, p.depth);
+    hipLaunchKernelGGL(k_accumulate, dim3(1), dim3(kShards), 0, st, s->d_counters, s->d_totals, level0_items ? pixels : 0u, p.depth,
+                       first ? 1u : 0u);
     HIP_TRY(hipGetLastError());
     return RTX_OK;
 }
@@ -1262,17 +1282,19 @@ int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_opts* opts, float
     p.canvas = d_rgb;
 
     HIP_TRY(hipEventRecord(s->ev_begin, st));
-    // Canvas starts black (canvas.zig:23-25); rows never rendered stay black.
-    HIP_TRY(hipMemsetAsync(d_rgb, 0, out_rows * W * 3 * sizeof(float), st));
+    // Canvas starts black (canvas.zig:23-25); rows never rendered stay black.  Every rendered
+    // pixel is written exactly once, so only a canvas with unrendered rows needs the fill.
+    if (!compact && plan.rows_local < H) HIP_TRY(hipMemsetAsync(d_rgb, 0, out_rows * W * 3 * sizeof(float), st));
+    // The shard counters are left at zero by k_accumulate; clear them anyway in case an earlier
+    // call on this scene stopped half way.
     HIP_TRY(hipMemsetAsync(s->d_counters, 0, sizeof(Counters), st));
-    HIP_TRY(hipMemsetAsync(s->d_totals, 0, sizeof(Totals), st));
 
     for (uint32_t row0 = 0; row0 < plan.rows_local; row0 += rows_per_batch) {
         const uint32_t n_rows = (plan.rows_local - row0 < rows_per_batch) ? plan.rows_local - row0 : rows_per_batch;
         p.row0 = row0;
         p.n_rows = n_rows;
         const uint32_t items = tiles_x * ((n_rows + 7u) / 8u) * 64u;
-        rc = run_levels<true>(s, p, cap, items, st, profile);
+        rc = run_levels<true>(s, p, cap, items, st, profile, row0 == 0);
         if (rc) return rc;
     }
     if (d_rgb8) {
@@ -1474,12 +1496,11 @@ int rtx_color_at(rtx_scene* s, const float* origins, const float* directions, ui
     HIP_TRY(hipMemcpyAsync(s->q_dir[0], directions, (size_t)n * 16, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(s->q_link[0], links.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(s->d_counters, 0, sizeof(Counters), st));
-    HIP_TRY(hipMemsetAsync(s->d_totals, 0, sizeof(Totals), st));
     Params p;
     fill_scene_params(s, p, depth);
     p.canvas = s->d_canvas;
     p.root_count = n;
-    rc = run_levels<false>(s, p, n, n, st, false);
+    rc = run_levels<false>(s, p, n, n, st, false, true);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(rgb_out, s->d_canvas, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
