@@ -36,6 +36,7 @@ import numpy as np
 import torch
 
 rta = importlib.import_module("ray-tracer_amd")
+tiling = importlib.import_module("ray-tracer_amd.tiling")
 
 WIDTH, HEIGHT = 1920, 1080
 SCENES = ["glass_spheres", "fresnel"]
@@ -129,19 +130,21 @@ def main():
     cams = [rta.flatten_camera(s.camera) for s in samples]
     strips = (STRIP_ROWS, n, rank) if n > 1 else None
     rows = [rta.rows_for(c, strips=strips) for c in cams]
-    max_rows = -(-HEIGHT // STRIP_ROWS // n) * STRIP_ROWS if n > 1 else HEIGHT  # equal-size gather slots
+    max_rows = tiling.slot_rows(HEIGHT, STRIP_ROWS, n) if n > 1 else HEIGHT  # equal-size gather slots
     rgb = [torch.zeros((max_rows, WIDTH, 3), dtype=torch.float32, device=dev) for _ in scenes]
     rgb8 = [torch.zeros((max_rows, WIDTH, 3), dtype=torch.uint8, device=dev) for _ in scenes]
-    gathered = None
+    gathered = full8 = None
     if n > 1 and rank == 0:
         gathered = [[torch.zeros_like(rgb8[0]) for _ in range(n)] for _ in scenes]
+        full8 = [torch.zeros((HEIGHT, WIDTH, 3), dtype=torch.uint8, device=dev) for _ in scenes]
 
     def frame(profile):
         for i, sc in enumerate(scenes):
             sc.render_device(cams[i], rgb[i].data_ptr(), rgb8[i].data_ptr(), stream=stream, strips=strips,
                              compact_rows=n > 1, profile=profile)
-            if n > 1:  # canvas gather: every peer sends its u8 strips straight to rank 0
-                dist.gather(rgb8[i], gathered[i] if rank == 0 else None, dst=0)
+            if n > 1:  # canvas gather: every peer sends its u8 strips straight to rank 0, which re-interleaves them
+                tiling.gather_canvas(rgb8[i], HEIGHT, STRIP_ROWS, out=full8[i] if rank == 0 else None,
+                                     slots=gathered[i] if rank == 0 else None)
 
     def fence():
         if n > 1:
