@@ -111,6 +111,23 @@ float rt_sin(float x);
 float rt_cos(float x);
 float rt_tan(float x);
 
+/* ---- OBJ ingest: obj.parseObjFile / ObjFile.toShapeGroup — src/obj_file.zig:45-62,77-147 (host only) ---- */
+
+enum {
+    RT_OBJ_INVALID_COMMAND = -10, /* ParserError.InvalidCommand (src/obj_file.zig:25-27,101,137,141,150) */
+    RT_OBJ_BAD_NUMBER      = -11, /* std.fmt.parseFloat / parseInt failed (:105-107,115) */
+    RT_OBJ_BAD_INDEX       = -12  /* vertex index out of range or a face with < 3 indices (a panic in the reference) */
+};
+typedef struct rt_obj rt_obj;
+/* Parse `len` bytes of OBJ text (`v`, `f`, `g` only). */
+int      rt_obj_parse(const char* text, uint64_t len, rt_obj** out);
+uint32_t rt_obj_vertex_count(const rt_obj* obj);
+uint32_t rt_obj_face_count(const rt_obj* obj);  /* triangles after fan triangulation */
+uint32_t rt_obj_group_count(const rt_obj* obj); /* named groups that hold faces */
+/* toShapeGroup; bound != 0 also runs Group.bound() (samples/teapot.zig:19).  The group is owned by `obj`. */
+int      rt_obj_to_group(rt_obj* obj, int bound, const rt_group** out);
+void     rt_obj_free(rt_obj* obj);
+
 /* ---- the reference's sample scenes (samples/<name>.zig), built through the C++ mirror --- */
 
 typedef struct rt_sample rt_sample;

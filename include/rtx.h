@@ -143,6 +143,8 @@ typedef struct rtx_opts {
     uint32_t strip_index;
     uint32_t compact_rows;
     uint32_t profile;      /* 1: time each kernel class with HIP events (adds syncs) */
+    uint32_t no_bvh;       /* 1: test every triangle of a group linearly (A/B check of the triangle BVH) */
+    uint32_t reserved;
 } rtx_opts;
 
 typedef struct rtx_stats {

@@ -67,7 +67,8 @@ class RtxCamera(C.Structure):
 
 class RtxOpts(C.Structure):
     _fields_ = [("depth", u32), ("rows_quirk", u32), ("batch_pixels", u32), ("strip_rows", u32),
-                ("strip_count", u32), ("strip_index", u32), ("compact_rows", u32), ("profile", u32)]
+                ("strip_count", u32), ("strip_index", u32), ("compact_rows", u32), ("profile", u32),
+                ("no_bvh", u32), ("reserved", u32)]
 
 
 class RtxStats(C.Structure):
@@ -135,6 +136,12 @@ _SIGNATURES = [
     ("rt_sin", f32, [f32]),
     ("rt_cos", f32, [f32]),
     ("rt_tan", f32, [f32]),
+    ("rt_obj_parse", C.c_int, [C.c_char_p, C.c_uint64, P(C.c_void_p)]),
+    ("rt_obj_vertex_count", u32, [C.c_void_p]),
+    ("rt_obj_face_count", u32, [C.c_void_p]),
+    ("rt_obj_group_count", u32, [C.c_void_p]),
+    ("rt_obj_to_group", C.c_int, [C.c_void_p, C.c_int, P(P(st.Group))]),
+    ("rt_obj_free", None, [C.c_void_p]),
     ("rt_sample_create", C.c_void_p, [C.c_char_p, u32, u32]),
     ("rt_sample_world", P(st.World), [C.c_void_p]),
     ("rt_sample_camera", P(st.Camera), [C.c_void_p]),
@@ -194,6 +201,43 @@ class Sample:
             self.handle = None
 
 
+class ObjFile:
+    """obj.parseObjFile + toShapeGroup (src/obj_file.zig): text -> rt_group owned by this object."""
+
+    def __init__(self, text, bound=True):
+        data = text.encode() if isinstance(text, str) else text
+        h = C.c_void_p()
+        rc = lib().rt_obj_parse(data, len(data), C.byref(h))
+        if rc != 0:
+            raise RtxError(rc, "OBJ parse error")
+        self.handle = h
+        g = P(st.Group)()
+        _check(lib().rt_obj_to_group(h, 1 if bound else 0, C.byref(g)))
+        self.group = g.contents
+        self.n_vertices = lib().rt_obj_vertex_count(h)
+        self.n_faces = lib().rt_obj_face_count(h)
+        self.n_groups = lib().rt_obj_group_count(h)
+
+    def __del__(self):
+        if getattr(self, "handle", None):
+            lib().rt_obj_free(self.handle)
+            self.handle = None
+
+
+def teapot_scene(obj_text, width=256, height=256, extra=None):
+    """samples/teapot.zig: the OBJ group (bounded) under its light and camera.
+
+    `extra` may add world-level shapes (dict of lists as for scene_types.make_world).
+    Returns (world, camera, keepalive)."""
+    import math
+
+    obj = ObjFile(obj_text, bound=True)
+    world, keep = st.make_world([0, 0, -10, 1], [1, 1, 1], groups=[obj.group], **(extra or {}))
+    cam = camera(width, height, float(np.float32(math.pi / 3.0)), (0, 3, -10, 1), (0, 0, 0, 1), (0, 1, 0, 0))
+    keep.append(obj)
+    return world, cam, keep
+
+
 SAMPLES = ["sphere_world", "glass_spheres", "fresnel", "cylinder_world", "cone", "cube", "reflective_floor",
            "skewed_triangle", "striped_scene", "sphere_on_plane"]
 
@@ -244,12 +288,13 @@ class Scene:
 
     __del__ = close
 
-    def render(self, cam, rows_quirk=True, depth=0, batch_pixels=0, strips=None, compact_rows=False, profile=False):
+    def render(self, cam, rows_quirk=True, depth=0, batch_pixels=0, strips=None, compact_rows=False, profile=False,
+               no_bvh=False):
         """render() — src/camera.zig:84-105 -> (canvas float32 [rows, W, 3], RtxStats)."""
         L = lib()
         rc = flatten_camera(cam) if isinstance(cam, st.Camera) else cam
         opts = RtxOpts(depth=depth, rows_quirk=1 if rows_quirk else 0, batch_pixels=batch_pixels,
-                       compact_rows=1 if compact_rows else 0, profile=1 if profile else 0)
+                       compact_rows=1 if compact_rows else 0, profile=1 if profile else 0, no_bvh=1 if no_bvh else 0)
         if strips is not None:
             opts.strip_rows, opts.strip_count, opts.strip_index = strips
         rows = u32()
@@ -266,7 +311,7 @@ class Scene:
         rc = flatten_camera(cam) if isinstance(cam, st.Camera) else cam
         opts = RtxOpts(depth=kw.get("depth", 0), rows_quirk=1 if kw.get("rows_quirk", True) else 0,
                        batch_pixels=kw.get("batch_pixels", 0), compact_rows=1 if kw.get("compact_rows", False) else 0,
-                       profile=1 if kw.get("profile", False) else 0)
+                       profile=1 if kw.get("profile", False) else 0, no_bvh=1 if kw.get("no_bvh", False) else 0)
         if kw.get("strips") is not None:
             opts.strip_rows, opts.strip_count, opts.strip_index = kw["strips"]
         stats = RtxStats() if want_stats else None

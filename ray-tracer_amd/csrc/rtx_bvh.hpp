@@ -1,0 +1,287 @@
+// rtx_bvh.hpp — host-side builder of the triangle BVH (new design: the reference has only
+// one optional AABB per Group, src/group.zig:24,58, and brute-forces every member).
+//
+// Contract: the BVH is a pure accelerator.  It only decides which triangles get tested; the
+// test itself is the reference's Moller-Trumbore arithmetic (src/triangle.zig:32-50) and the
+// winner is still the minimum (t, insertion index), so results equal brute force.  To never
+// cull a triangle the f32 test would accept, boxes are built in double precision from the
+// world-space vertices and padded; the device slab test adds its own slack.
+//
+// Layout: "threaded" pre-order array — a node's first child is the next node, `skip` is the
+// index after its subtree — so traversal needs no per-lane stack.
+#pragma once
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+#include "../../include/rtx.h"
+
+namespace rtx_bvh {
+
+constexpr uint32_t kNoLeaf = 0xFFFFFFFFu;
+constexpr uint32_t kLeafTris = 4;
+constexpr uint32_t kMinTris = 16;  // shorter triangle runs stay on the linear path
+
+struct Node {  // 32 bytes
+    float bmin[3];
+    uint32_t skip;  // absolute index of the first node after this subtree
+    float bmax[3];
+    uint32_t leaf;  // kNoLeaf, or (first_tri << 3) | count with count <= kLeafTris
+};
+
+struct Tri {  // 48 bytes, in leaf order
+    float p0[3];
+    uint32_t shape;  // index into the flattened shape array == insertion order
+    float e0[3];
+    uint32_t flags;  // RTX_SHAPE_* of that shape
+    float e1[3];
+    uint32_t pad;
+};
+
+struct Box {
+    double mn[3], mx[3];
+    void reset() {
+        for (int k = 0; k < 3; ++k) {
+            mn[k] = INFINITY;
+            mx[k] = -INFINITY;
+        }
+    }
+    void add(const double p[3]) {
+        for (int k = 0; k < 3; ++k) {
+            mn[k] = std::min(mn[k], p[k]);
+            mx[k] = std::max(mx[k], p[k]);
+        }
+    }
+    void add(const Box& b) {
+        for (int k = 0; k < 3; ++k) {
+            mn[k] = std::min(mn[k], b.mn[k]);
+            mx[k] = std::max(mx[k], b.mx[k]);
+        }
+    }
+    double area() const {
+        const double x = mx[0] - mn[0], y = mx[1] - mn[1], z = mx[2] - mn[2];
+        return x * y + y * z + z * x;
+    }
+};
+
+struct Prim {
+    Box box;
+    double centroid[3];
+    uint32_t shape;
+};
+
+// 4x4 inverse in double (Gauss-Jordan); returns false if singular.
+inline bool invert4(const double in[16], double out[16]) {
+    double a[4][8];
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) {
+            a[r][c] = in[r * 4 + c];
+            a[r][4 + c] = r == c ? 1.0 : 0.0;
+        }
+    for (int c = 0; c < 4; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < 4; ++r)
+            if (std::fabs(a[r][c]) > std::fabs(a[piv][c])) piv = r;
+        if (a[piv][c] == 0.0) return false;
+        if (piv != c)
+            for (int k = 0; k < 8; ++k) std::swap(a[piv][k], a[c][k]);
+        const double d = a[c][c];
+        for (int k = 0; k < 8; ++k) a[c][k] /= d;
+        for (int r = 0; r < 4; ++r) {
+            if (r == c) continue;
+            const double f = a[r][c];
+            if (f != 0.0)
+                for (int k = 0; k < 8; ++k) a[r][k] -= f * a[c][k];
+        }
+    }
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) out[r * 4 + c] = a[r][4 + c];
+    return true;
+}
+
+// World-space box of one triangle shape; false if it cannot be bounded (then no BVH is built
+// for its run and the run stays on the linear path).
+inline bool bound_triangle(const rtx_shape& s, uint32_t index, Prim& out) {
+    double inv[16], m[16];
+    for (int k = 0; k < 16; ++k) inv[k] = s.inverse[k];
+    if (!invert4(inv, m)) return false;
+    double v[3][3];
+    for (int k = 0; k < 3; ++k) {
+        v[0][k] = s.p0[k];
+        v[1][k] = (double)s.p0[k] + s.e0[k];
+        v[2][k] = (double)s.p0[k] + s.e1[k];
+    }
+    out.box.reset();
+    for (int i = 0; i < 3; ++i) {
+        double w[3];
+        for (int r = 0; r < 3; ++r) w[r] = m[r * 4 + 0] * v[i][0] + m[r * 4 + 1] * v[i][1] + m[r * 4 + 2] * v[i][2] + m[r * 4 + 3];
+        for (int r = 0; r < 3; ++r)
+            if (!std::isfinite(w[r])) return false;
+        out.box.add(w);
+    }
+    // Padding: the f32 test can accept points a few ulp outside the exact triangle; the slack
+    // scales with the coordinates involved.
+    for (int k = 0; k < 3; ++k) {
+        const double mag = std::max(std::fabs(out.box.mn[k]), std::fabs(out.box.mx[k]));
+        const double ext = out.box.mx[k] - out.box.mn[k];
+        const double pad = 1e-4 * ext + 1e-5 * mag + 1e-6;
+        out.box.mn[k] -= pad;
+        out.box.mx[k] += pad;
+        out.centroid[k] = 0.5 * (out.box.mn[k] + out.box.mx[k]);
+    }
+    out.shape = index;
+    return true;
+}
+
+struct Builder {
+    std::vector<Node>& nodes;
+    std::vector<Tri>& tris;
+    const rtx_shape* shapes;
+    std::vector<Prim> prims;
+
+    static float down(double x) { return std::nextafter((float)x, -INFINITY); }
+    static float up(double x) { return std::nextafter((float)x, INFINITY); }
+
+    void emit_box(Node& n, const Box& b) {
+        for (int k = 0; k < 3; ++k) {
+            n.bmin[k] = down(b.mn[k]);
+            n.bmax[k] = up(b.mx[k]);
+        }
+    }
+
+    void build(size_t lo, size_t hi) {
+        Box box, cbox;
+        box.reset();
+        cbox.reset();
+        for (size_t i = lo; i < hi; ++i) {
+            box.add(prims[i].box);
+            cbox.add(prims[i].centroid);
+        }
+        const size_t me = nodes.size();
+        nodes.push_back(Node{});
+        emit_box(nodes[me], box);
+        const size_t n = hi - lo;
+        int axis = 0;
+        double ext = -1;
+        for (int k = 0; k < 3; ++k)
+            if (cbox.mx[k] - cbox.mn[k] > ext) {
+                ext = cbox.mx[k] - cbox.mn[k];
+                axis = k;
+            }
+        if (n <= kLeafTris || !(ext > 0)) {
+            // Leaves hold at most 7 triangles (3 bits); degenerate centroid sets are chunked.
+            if (n <= 7) {
+                nodes[me].leaf = (uint32_t)((tris.size() << 3) | n);
+                for (size_t i = lo; i < hi; ++i) {
+                    const rtx_shape& s = shapes[prims[i].shape];
+                    Tri t{};
+                    for (int k = 0; k < 3; ++k) {
+                        t.p0[k] = s.p0[k];
+                        t.e0[k] = s.e0[k];
+                        t.e1[k] = s.e1[k];
+                    }
+                    t.shape = prims[i].shape;
+                    t.flags = s.flags;
+                    tris.push_back(t);
+                }
+                nodes[me].skip = (uint32_t)nodes.size();
+                return;
+            }
+            const size_t mid = lo + n / 2;
+            nodes[me].leaf = kNoLeaf;
+            build(lo, mid);
+            build(mid, hi);
+            nodes[me].skip = (uint32_t)nodes.size();
+            return;
+        }
+        // Binned SAH on the widest centroid axis.
+        constexpr int kBins = 16;
+        Box bbox[kBins];
+        size_t bcount[kBins] = {0};
+        for (auto& b : bbox) b.reset();
+        const double scale = kBins / ext;
+        auto bin_of = [&](const Prim& p) {
+            int b = (int)((p.centroid[axis] - cbox.mn[axis]) * scale);
+            return b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+        };
+        for (size_t i = lo; i < hi; ++i) {
+            const int b = bin_of(prims[i]);
+            bbox[b].add(prims[i].box);
+            bcount[b]++;
+        }
+        double best = INFINITY;
+        int best_split = -1;
+        for (int sidx = 1; sidx < kBins; ++sidx) {
+            Box l, r;
+            l.reset();
+            r.reset();
+            size_t nl = 0, nr = 0;
+            for (int b = 0; b < sidx; ++b)
+                if (bcount[b]) {
+                    l.add(bbox[b]);
+                    nl += bcount[b];
+                }
+            for (int b = sidx; b < kBins; ++b)
+                if (bcount[b]) {
+                    r.add(bbox[b]);
+                    nr += bcount[b];
+                }
+            if (!nl || !nr) continue;
+            const double cost = l.area() * (double)nl + r.area() * (double)nr;
+            if (cost < best) {
+                best = cost;
+                best_split = sidx;
+            }
+        }
+        size_t mid;
+        if (best_split < 0) {
+            mid = lo + n / 2;
+            std::nth_element(prims.begin() + lo, prims.begin() + mid, prims.begin() + hi,
+                             [&](const Prim& a, const Prim& b) { return a.centroid[axis] < b.centroid[axis]; });
+        } else {
+            // stable_partition keeps the build deterministic
+            auto it = std::stable_partition(prims.begin() + lo, prims.begin() + hi,
+                                            [&](const Prim& p) { return bin_of(p) < best_split; });
+            mid = (size_t)(it - prims.begin());
+        }
+        nodes[me].leaf = kNoLeaf;
+        build(lo, mid);
+        build(mid, hi);
+        nodes[me].skip = (uint32_t)nodes.size();
+    }
+};
+
+// Build a BVH over shapes [first, first + count) (all triangles).  Appends to nodes/tris and
+// returns the root index, or kNoLeaf if the run cannot be bounded.
+inline uint32_t build_run(const rtx_shape* shapes, uint32_t first, uint32_t count, std::vector<Node>& nodes,
+                          std::vector<Tri>& tris) {
+    Builder b{nodes, tris, shapes, {}};
+    b.prims.reserve(count);
+    for (uint32_t i = 0; i < count; ++i) {
+        const rtx_shape& s = shapes[first + i];
+        // A triangle whose e0 is exactly zero can never be hit: det = dot(e0, ...) = 0 fails the
+        // |det| < epsilon test (src/triangle.zig:36-37).  The OBJ fan emits one per polygon.
+        if (s.e0[0] == 0.0f && s.e0[1] == 0.0f && s.e0[2] == 0.0f && s.e0[3] == 0.0f) continue;
+        Prim p;
+        if (!bound_triangle(s, first + i, p)) return kNoLeaf;
+        b.prims.push_back(p);
+    }
+    const uint32_t root = (uint32_t)nodes.size();
+    if (b.prims.empty()) {  // nothing can be hit: an empty leaf
+        Node n{};
+        n.leaf = (uint32_t)(tris.size() << 3);
+        n.skip = root + 1;
+        for (int k = 0; k < 3; ++k) {
+            n.bmin[k] = INFINITY;
+            n.bmax[k] = -INFINITY;
+        }
+        nodes.push_back(n);
+        return root;
+    }
+    b.build(0, b.prims.size());
+    return root;
+}
+
+}  // namespace rtx_bvh

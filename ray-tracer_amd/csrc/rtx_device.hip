@@ -35,6 +35,7 @@
 #include "../../include/rt_scene.h"
 #include "../../include/rtx.h"
 #include "../host/rt_libm.hpp"
+#include "rtx_bvh.hpp"
 
 namespace {
 
@@ -113,6 +114,8 @@ struct Params {
     const rtx_node* nodes;
     const rtx_material* materials;
     const rtx_pattern* patterns;
+    const rtx_bvh::Node* bvh_nodes;  // triangle BVHs of all gate nodes, threaded pre-order
+    const rtx_bvh::Tri* bvh_tris;
     uint32_t n_nodes;
     uint32_t n_shapes;
     uint32_t n_materials;
@@ -159,10 +162,6 @@ __device__ __forceinline__ V4 neg(V4 a) { return v4(-a.x, -a.y, -a.z, -a.w); }
 
 // tup.dot — four lanes, left to right (src/tuple.zig:38-40)
 __device__ __forceinline__ float dot(V4 u, V4 v) { return u.x * v.x + u.y * v.y + u.z * v.z + u.w * v.w; }
-// tup.cross — w lane 0 (src/tuple.zig:42-48)
-__device__ __forceinline__ V4 cross(V4 u, V4 v) {
-    return v4(u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x, 0.0f);
-}
 __device__ __forceinline__ float magnitude(V4 v) { return sqrtf(dot(v, v)); }          // tuple.zig:50-52
 __device__ __forceinline__ V4 normalize(V4 v) { return divs(v, magnitude(v)); }        // tuple.zig:54-56
 __device__ __forceinline__ V4 reflect(V4 incident, V4 normal) {                        // tuple.zig:58-77
@@ -218,20 +217,27 @@ struct ClosestVisitor {
         c.pred_t = 0.0f;
         c.pred_idx = kNone;
     }
+    // Ties are decided on the insertion index explicitly (lowest wins for the hit, highest for
+    // the predecessor), so the result does not depend on the order shapes are visited in —
+    // the BVH visits triangles out of insertion order.
     __device__ __forceinline__ void hit(float t, uint32_t s) {
-        if (t >= 0.0f && (c.idx == kNone || t < c.t)) {
+        if (t >= 0.0f && (c.idx == kNone || t < c.t || (t == c.t && s < c.idx))) {
             c.t = t;
             c.idx = s;
         }
     }
     __device__ __forceinline__ void pred(float t, uint32_t s) {
-        if (TRACK && t < 0.0f && (c.pred_idx == kNone || t >= c.pred_t)) {
+        if (TRACK && t < 0.0f && (c.pred_idx == kNone || t > c.pred_t || (t == c.pred_t && s > c.pred_idx))) {
             c.pred_t = t;
             c.pred_idx = s;
         }
     }
     static constexpr bool kTrack = TRACK;
     __device__ __forceinline__ bool done() const { return false; }
+    // Range of t a BVH subtree must overlap to matter: with predecessor tracking the whole
+    // line counts (negative roots feed n1); otherwise only [0, current best].
+    __device__ __forceinline__ float t_lo() const { return TRACK ? -INFINITY : 0.0f; }
+    __device__ __forceinline__ float t_hi() const { return c.idx == kNone ? INFINITY : c.t; }
 };
 
 // isShadowed (src/world.zig:97-120): the nearest t >= 0 is < distance  <=>  some root lies
@@ -245,6 +251,8 @@ struct ShadowVisitor {
     __device__ __forceinline__ void pred(float, uint32_t) {}
     static constexpr bool kTrack = false;
     __device__ __forceinline__ bool done() const { return found; }
+    __device__ __forceinline__ float t_lo() const { return 0.0f; }
+    __device__ __forceinline__ float t_hi() const { return distance; }
 };
 
 struct TMinMax {
@@ -297,16 +305,39 @@ __device__ __forceinline__ void offer_roots(V& v, uint32_t s, bool n1_visible, c
     }
 }
 
+constexpr uint32_t kShapeIdentity = 1u << 8;  // library-internal: the inverse is exactly the identity
+
+// Triangle.intersect (src/triangle.zig:32-50, Moller-Trumbore) on the object-space ray.
+// cross() has w = 0, so the w lanes of e0 / e1 / p0_to_origin only ever add an exact zero to
+// the dots; they are left out.
+__device__ __forceinline__ bool triangle_root(V4 ro, V4 rd, const float* p0, const float* e0, const float* e1, float& t) {
+    const float cx = rd.y * e1[2] - rd.z * e1[1], cy = rd.z * e1[0] - rd.x * e1[2], cz = rd.x * e1[1] - rd.y * e1[0];
+    const float det = e0[0] * cx + e0[1] * cy + e0[2] * cz;
+    if (fabsf(det) < kEpsilon) return false;
+    const float f = 1.0f / det;
+    const float px = ro.x - p0[0], py = ro.y - p0[1], pz = ro.z - p0[2];
+    const float u = f * (px * cx + py * cy + pz * cz);
+    if (u < 0.0f || u > 1.0f) return false;
+    const float ox = py * e0[2] - pz * e0[1], oy = pz * e0[0] - px * e0[2], oz = px * e0[1] - py * e0[0];
+    const float vv = f * (rd.x * ox + rd.y * oy + rd.z * oz);
+    if (vv < 0.0f || (u + vv) > 1.0f) return false;
+    t = f * (e1[0] * ox + e1[1] * oy + e1[2] * oz);
+    return true;
+}
+
 // Shape.intersect for every shape type; `sh` is wave-uniform (scalar loads), the ray is
 // per lane.  o/d are the world-space ray; the object-space ray is r.transform(inverse)
 // (src/ray.zig:13-18) with all four lanes kept.
 template <class V>
 __device__ __forceinline__ void intersect_shape(V& v, const RT_CONST rtx_shape& sh, uint32_t s, V4 o, V4 d) {
-    float inv[16];
+    V4 ro = o, rd = d;
+    if (!(sh.flags & kShapeIdentity)) {  // x * identity is x (up to the sign of a zero): skip it
+        float inv[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) inv[k] = sh.inverse[k];
-    const V4 ro = mul_mat(inv, o);
-    const V4 rd = mul_mat(inv, d);
+        for (int k = 0; k < 16; ++k) inv[k] = sh.inverse[k];
+        ro = mul_mat(inv, o);
+        rd = mul_mat(inv, d);
+    }
     const bool n1_visible = !(sh.flags & RTX_SHAPE_N1_INVISIBLE);
     float t[4];
     bool ok[4] = {false, false, false, false};
@@ -415,35 +446,78 @@ __device__ __forceinline__ void intersect_shape(V& v, const RT_CONST rtx_shape& 
         }
         break;
     }
-    default: {  // RTX_TRIANGLE, src/triangle.zig:32-50 (Moller-Trumbore)
-        const V4 e0 = v4(sh.e0[0], sh.e0[1], sh.e0[2], sh.e0[3]);
-        const V4 e1 = v4(sh.e1[0], sh.e1[1], sh.e1[2], sh.e1[3]);
-        const V4 p0 = v4(sh.p0[0], sh.p0[1], sh.p0[2], sh.p0[3]);
-        const V4 dir_cross_e1 = cross(rd, e1);
-        const float det = dot(e0, dir_cross_e1);
-        if (!(fabsf(det) < kEpsilon)) {
-            const float f = 1.0f / det;
-            const V4 p0_to_origin = sub(ro, p0);
-            const float u = f * dot(p0_to_origin, dir_cross_e1);
-            if (!(u < 0.0f || u > 1.0f)) {
-                const V4 origin_cross_e0 = cross(p0_to_origin, e0);
-                const float vv = f * dot(rd, origin_cross_e0);
-                if (!(vv < 0.0f || (u + vv) > 1.0f)) {
-                    t[0] = f * dot(e1, origin_cross_e0);
-                    ok[0] = true;
-                }
-            }
+    default: {  // RTX_TRIANGLE
+        float p0[3], e0[3], e1[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            p0[k] = sh.p0[k];
+            e0[k] = sh.e0[k];
+            e1[k] = sh.e1[k];
         }
+        ok[0] = triangle_root(ro, rd, p0, e0, e1, t[0]);
         break;
     }
     }
     offer_roots(v, s, n1_visible, t, ok);
 }
 
+// Per-lane walk of one triangle BVH (threaded pre-order, no stack).  Only culling happens
+// here; every surviving triangle goes through the reference's test and the visitor.
+template <class V>
+__device__ __forceinline__ void traverse_bvh(V& v, const Params& p, uint32_t root, V4 o, V4 d) {
+    const float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
+    const rtx_bvh::Node* nodes = p.bvh_nodes;
+    uint32_t n = root;
+    const uint32_t end = nodes[root].skip;
+    while (n < end && !v.done()) {
+        const float4 a = *reinterpret_cast<const float4*>(&nodes[n].bmin[0]);
+        const float4 b = *reinterpret_cast<const float4*>(&nodes[n].bmax[0]);
+        const uint32_t skip = __float_as_uint(a.w), leaf = __float_as_uint(b.w);
+        // slab test; a NaN (0 * inf) drops out of fmin/fmax like in the reference's checkAxis
+        const float x0 = (a.x - o.x) * ix, x1 = (b.x - o.x) * ix;
+        const float y0 = (a.y - o.y) * iy, y1 = (b.y - o.y) * iy;
+        const float z0 = (a.z - o.z) * iz, z1 = (b.z - o.z) * iz;
+        const float tmin = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+        const float tmax = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+        const float slack = 1e-5f * (fabsf(tmin) + fabsf(tmax)) + 1e-6f;
+        const bool overlap = (tmin - slack <= tmax + slack) && (tmax + slack >= v.t_lo()) && (tmin - slack <= v.t_hi());
+        if (!overlap) {
+            n = skip;
+            continue;
+        }
+        if (leaf != rtx_bvh::kNoLeaf) {
+            const uint32_t first = leaf >> 3, count = leaf & 7u;
+            for (uint32_t k = 0; k < count; ++k) {
+                const rtx_bvh::Tri* tr = &p.bvh_tris[first + k];
+                const float4 q0 = *reinterpret_cast<const float4*>(&tr->p0[0]);
+                const float4 q1 = *reinterpret_cast<const float4*>(&tr->e0[0]);
+                const float4 q2 = *reinterpret_cast<const float4*>(&tr->e1[0]);
+                const uint32_t shape = __float_as_uint(q0.w), flags = __float_as_uint(q1.w);
+                V4 ro = o, rd = d;
+                if (!(flags & kShapeIdentity)) {
+                    const float* inv = p.shapes[shape].inverse;
+                    ro = mul_mat(inv, o);
+                    rd = mul_mat(inv, d);
+                }
+                const float p0[3] = {q0.x, q0.y, q0.z}, e0[3] = {q1.x, q1.y, q1.z}, e1[3] = {q2.x, q2.y, q2.z};
+                float t;
+                if (triangle_root(ro, rd, p0, e0, e1, t)) {
+                    v.hit(t, shape);
+                    if (V::kTrack && !(flags & RTX_SHAPE_N1_INVISIBLE)) v.pred(t, shape);
+                }
+            }
+            n = skip;
+        } else {
+            n = n + 1;
+        }
+    }
+}
+
 // World.intersect + Group.intersect (src/world.zig:38-47, src/group.zig:55-87) over the
 // flattened node/shape arrays.  The node and shape loops are wave-uniform (records come in
 // through scalar loads); a lane whose ray failed a group's box is parked until the loop
-// leaves that group's subtree.  `lane_on` is false for padding lanes.
+// leaves that group's subtree.  `lane_on` is false for padding lanes.  A node whose triangle
+// run has a BVH tests only its `n_linear` leading shapes linearly.
 template <class V>
 __device__ __forceinline__ void traverse(V& v, const Params& p, V4 o, V4 d, bool lane_on) {
     uint32_t parked_until = lane_on ? 0u : kNone;  // node index at which this lane wakes up
@@ -457,11 +531,13 @@ __device__ __forceinline__ void traverse(V& v, const Params& p, V4 o, V4 d, bool
             active = false;
         }
         if (__ballot(active) == 0ull) continue;
+        const uint32_t bvh_root = node.reserved[0];  // root + 1, 0 = no BVH
         const uint32_t first = node.first_shape;
-        const uint32_t last = first + node.n_shapes;
+        const uint32_t last = first + (bvh_root ? node.reserved[1] : node.n_shapes);
         for (uint32_t s = first; s < last; ++s) {
             if (active) intersect_shape(v, shapes[s], s, o, d);
         }
+        if (bvh_root && active) traverse_bvh(v, p, bvh_root - 1u, o, d);
     }
 }
 
@@ -973,7 +1049,11 @@ struct rtx_scene {
     int device = 0;
     hipStream_t stream = nullptr;
     rtx_shape* d_shapes = nullptr;
-    rtx_node* d_nodes = nullptr;
+    rtx_node* d_nodes = nullptr;         // gates with BVH links (reserved[0] = root + 1, reserved[1] = linear shapes)
+    rtx_node* d_nodes_linear = nullptr;  // the same gates, brute force only (rtx_opts.no_bvh)
+    rtx_bvh::Node* d_bvh_nodes = nullptr;
+    rtx_bvh::Tri* d_bvh_tris = nullptr;
+    uint32_t n_bvh_nodes = 0, n_bvh_tris = 0;
     rtx_material* d_materials = nullptr;
     rtx_pattern* d_patterns = nullptr;
     uint32_t n_shapes = 0, n_nodes = 0, n_materials = 0, n_patterns = 0;
@@ -1138,6 +1218,8 @@ void fill_scene_params(const rtx_scene* s, Params& p, uint32_t depth) {
     std::memset(&p, 0, sizeof p);
     p.shapes = s->d_shapes;
     p.nodes = s->d_nodes;
+    p.bvh_nodes = s->d_bvh_nodes;
+    p.bvh_tris = s->d_bvh_tris;
     p.materials = s->d_materials;
     p.patterns = s->d_patterns;
     p.n_nodes = s->n_nodes;
@@ -1269,6 +1351,7 @@ int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_opts* opts, float
 
     Params p;
     fill_scene_params(s, p, depth);
+    if (opts && opts->no_bvh) p.nodes = s->d_nodes_linear;
     std::memcpy(p.cam_inv, cam->inverse_transform, sizeof p.cam_inv);
     p.half_width = cam->half_width;
     p.half_height = cam->half_height;
@@ -1402,8 +1485,38 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out) {
         if (bytes) e = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
         return e;
     };
-    HIP_TRY_S(upload((void**)&s->d_shapes, desc->shapes, sizeof(rtx_shape) * desc->n_shapes));
-    HIP_TRY_S(upload((void**)&s->d_nodes, desc->nodes, sizeof(rtx_node) * desc->n_nodes));
+    // Library-side derived data: identity flags and one BVH per long triangle run.
+    std::vector<rtx_shape> shapes(desc->shapes, desc->shapes + desc->n_shapes);
+    std::vector<rtx_node> nodes(desc->nodes, desc->nodes + desc->n_nodes);
+    static const float kIdentity[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    for (rtx_shape& sh : shapes) {
+        bool ident = true;
+        for (int k = 0; k < 16; ++k) ident = ident && sh.inverse[k] == kIdentity[k];
+        sh.flags &= 0xFFu;  // bits above are the library's
+        if (ident) sh.flags |= kShapeIdentity;
+    }
+    for (rtx_node& n : nodes) n.reserved[0] = n.reserved[1] = 0;
+    std::vector<rtx_node> linear = nodes;
+    std::vector<rtx_bvh::Node> bvh_nodes;
+    std::vector<rtx_bvh::Tri> bvh_tris;
+    for (rtx_node& n : nodes) {
+        // shapes of a node are in type order, so its triangles are the tail of its range
+        uint32_t n_lin = 0;
+        while (n_lin < n.n_shapes && shapes[n.first_shape + n_lin].type != RTX_TRIANGLE) ++n_lin;
+        const uint32_t n_tri = n.n_shapes - n_lin;
+        if (n_tri < rtx_bvh::kMinTris) continue;
+        const uint32_t root = rtx_bvh::build_run(shapes.data(), n.first_shape + n_lin, n_tri, bvh_nodes, bvh_tris);
+        if (root == rtx_bvh::kNoLeaf) continue;
+        n.reserved[0] = root + 1;
+        n.reserved[1] = n_lin;
+    }
+    s->n_bvh_nodes = (uint32_t)bvh_nodes.size();
+    s->n_bvh_tris = (uint32_t)bvh_tris.size();
+    HIP_TRY_S(upload((void**)&s->d_shapes, shapes.data(), sizeof(rtx_shape) * shapes.size()));
+    HIP_TRY_S(upload((void**)&s->d_nodes, nodes.data(), sizeof(rtx_node) * nodes.size()));
+    HIP_TRY_S(upload((void**)&s->d_nodes_linear, linear.data(), sizeof(rtx_node) * linear.size()));
+    HIP_TRY_S(upload((void**)&s->d_bvh_nodes, bvh_nodes.data(), sizeof(rtx_bvh::Node) * bvh_nodes.size()));
+    HIP_TRY_S(upload((void**)&s->d_bvh_tris, bvh_tris.data(), sizeof(rtx_bvh::Tri) * bvh_tris.size()));
     HIP_TRY_S(upload((void**)&s->d_materials, desc->materials, sizeof(rtx_material) * desc->n_materials));
     HIP_TRY_S(upload((void**)&s->d_patterns, desc->patterns, sizeof(rtx_pattern) * desc->n_patterns));
     HIP_TRY_S(hipMalloc(&s->d_counters, sizeof(Counters)));
@@ -1421,6 +1534,9 @@ void rtx_scene_destroy(rtx_scene* s) {
     if (s->d_canvas) (void)hipFree(s->d_canvas);
     if (s->d_shapes) (void)hipFree(s->d_shapes);
     if (s->d_nodes) (void)hipFree(s->d_nodes);
+    if (s->d_nodes_linear) (void)hipFree(s->d_nodes_linear);
+    if (s->d_bvh_nodes) (void)hipFree(s->d_bvh_nodes);
+    if (s->d_bvh_tris) (void)hipFree(s->d_bvh_tris);
     if (s->d_materials) (void)hipFree(s->d_materials);
     if (s->d_patterns) (void)hipFree(s->d_patterns);
     if (s->d_counters) (void)hipFree(s->d_counters);

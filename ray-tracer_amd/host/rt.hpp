@@ -147,6 +147,7 @@ struct Group {
 // A view of Groups as the C ABI's rt_group tree; owns the rt_group arrays.
 struct GroupView {
     std::vector<std::vector<rt_group>> storage;
+    std::vector<Group> keep;  // optional: groups this view owns
     const rt_group* build(const std::vector<Group>& groups);
 };
 

@@ -208,3 +208,60 @@ def test_invalid_arguments_are_rejected():
     with pytest.raises(rta.RtxError):
         scene.render(s.camera, strips=(8, 2, 2))
     scene.close()
+
+
+# ---- OBJ meshes: group gate + triangle BVH (new design) must equal brute force and the oracle ----
+
+ROOT = __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+
+
+def _teapot_text(level=1):
+    import subprocess
+    import sys
+
+    if level == 1:
+        return open(ROOT + "/samples/teapot.obj").read()
+    return subprocess.run([sys.executable, ROOT + "/samples/make_teapot_obj.py", str(level)], capture_output=True,
+                          text=True, check=True).stdout
+
+
+def test_teapot_matches_oracle_with_and_without_bvh():
+    world, cam, keep = rta.teapot_scene(_teapot_text(), 72, 72)
+    ref, counts = o.render(cam, world)
+    scene = rta.Scene(world)
+    gpu, stats = scene.render(cam)
+    compare(gpu, ref, "teapot (BVH)")
+    lin, stats_lin = scene.render(cam, no_bvh=True)
+    compare(lin, ref, "teapot (linear)")
+    assert stats.rays_total == counts.total == stats_lin.rays_total
+    scene.close()
+
+
+def test_teapot_with_glass_and_mirror_matches_oracle():
+    """The composite of BASELINE.json's stress config at test size: teapot group + the two glass
+    spheres + a reflective checkered floor; n1 tracking forces whole-line BVH traversal."""
+    g = rta.Sample("glass_spheres")
+    f = rta.Sample("reflective_floor")
+    spheres = [g.world.spheres[0], g.world.spheres[1]]
+    for s_ in spheres:
+        s_.common_attrs.transform = su.compose(su.translation(2.2, 1.0, -3.0), st.Mat4.from_rows(s_.common_attrs.transform.to_numpy()))
+    floor = f.world.planes[0]
+    world, cam, keep = rta.teapot_scene(_teapot_text(), 80, 64, extra={"spheres": spheres, "planes": [floor]})
+    ref, counts = o.render(cam, world)
+    scene = rta.Scene(world)
+    gpu, stats = scene.render(cam)
+    compare(gpu, ref, "teapot + glass + floor (BVH)")
+    lin, _ = scene.render(cam, no_bvh=True)
+    assert lin.tobytes() == gpu.tobytes()
+    assert stats.rays_total == counts.total
+    scene.close()
+
+
+def test_bvh_equals_brute_force_at_full_size():
+    world, cam, keep = rta.teapot_scene(_teapot_text(2), 960, 540)
+    scene = rta.Scene(world)
+    a, sa = scene.render(cam)
+    b, sb = scene.render(cam, no_bvh=True)
+    assert a.tobytes() == b.tobytes() and sa.rays_total == sb.rays_total
+    assert sa.rays_shadow > 10000
+    scene.close()
