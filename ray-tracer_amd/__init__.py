@@ -238,6 +238,35 @@ def teapot_scene(obj_text, width=256, height=256, extra=None):
     return world, cam, keep
 
 
+def composite_scene(obj_text, width=7680, height=4320):
+    """The scaled stress scene of BASELINE.json configs[4] — NOT a reference scene; frozen here:
+    the teapot group (samples/teapot.zig) standing on reflective_floor's checkered mirror plane,
+    glass_spheres' outer/inner glass pair to its right, reflective_floor's red sphere to its
+    left, teapot.zig's camera, light at (-5, 10, -10)."""
+    import math
+
+    def moved(shape, x, y, z):
+        out = st.Sphere(shape.common_attrs)
+        m = out.common_attrs.transform.to_numpy().copy()
+        t = np.eye(4, dtype=np.float32)
+        t[:3, 3] = [x, y, z]
+        mm = st.Mat4()
+        lib().rt_mat_mul(C.byref(st.Mat4.from_rows(t)), C.byref(st.Mat4.from_rows(m)), C.byref(mm))
+        out.common_attrs.transform = mm
+        return out
+
+    glass = Sample("glass_spheres")
+    floor = Sample("reflective_floor")
+    spheres = [moved(glass.world.spheres[0], 4.2, 1.0, -1.5), moved(glass.world.spheres[1], 4.2, 1.0, -1.5),
+               moved(floor.world.spheres[0], -4.0, 0.0, -2.0)]
+    obj = ObjFile(obj_text, bound=True)
+    world, keep = st.make_world([-5, 10, -10, 1], [1, 1, 1], groups=[obj.group], spheres=spheres,
+                                planes=[floor.world.planes[0]])
+    cam = camera(width, height, float(np.float32(math.pi / 3.0)), (0, 3, -10, 1), (0, 0, 0, 1), (0, 1, 0, 0))
+    keep += [obj, glass, floor]
+    return world, cam, keep
+
+
 SAMPLES = ["sphere_world", "glass_spheres", "fresnel", "cylinder_world", "cone", "cube", "reflective_floor",
            "skewed_triangle", "striped_scene", "sphere_on_plane"]
 

@@ -16,10 +16,25 @@ w = int(sys.argv[2]) if len(sys.argv) > 2 else 1920
 h = int(sys.argv[3]) if len(sys.argv) > 3 else 1080
 frames = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 batch = int(sys.argv[5]) if len(sys.argv) > 5 else 0
-s = rta.Sample(name, w, h)
-scene = rta.Scene(s.world)
+no_bvh = os.environ.get("RTX_NO_BVH") == "1"
+if name.split(":")[0] in ("teapot", "composite"):
+    import subprocess
+
+    level = name.split(":")[1] if ":" in name else "1"
+    text = subprocess.run([sys.executable, os.path.join(ROOT, "samples", "make_teapot_obj.py"), level],
+                          capture_output=True, text=True, check=True).stdout
+    world, cam, keep = (rta.teapot_scene if name.startswith("teapot") else rta.composite_scene)(text, w, h)
+else:
+    s = rta.Sample(name, w, h)
+    world, cam = s.world, s.camera
+scene = rta.Scene(world)
+print("shapes", scene.n_shapes)
 for i in range(frames):
-    canvas, st = scene.render(s.camera, batch_pixels=batch, profile=True)
+    canvas, st = scene.render(cam, batch_pixels=batch, profile=True, no_bvh=no_bvh)
+if os.environ.get("RTX_SAVE"):
+    import numpy as np
+
+    np.save(os.environ["RTX_SAVE"], rta.to_ppm_bytes(canvas))
 print(name, w, h, "rays", st.rays_primary, st.rays_shadow, st.rays_secondary, "levels", list(st.level_rays),
       "hits", list(st.level_hits), "ms_total %.3f trace %.3f (%d launches) combine %.3f" % (
           st.ms_total, st.ms_trace_shade, st.launches_trace_shade, st.ms_combine))
