@@ -133,6 +133,11 @@ void     rt_obj_free(rt_obj* obj);
 typedef struct rt_sample rt_sample;
 /* width/height 0 -> the sample's shipped resolution.  NULL if the name is unknown. */
 rt_sample*       rt_sample_create(const char* name, uint32_t width, uint32_t height);
+/* The two scenes built around an OBJ mesh, from `len` bytes of OBJ text: "teapot"
+ * (samples/teapot.zig:7-36; rt_sample_create("teapot") reads ./teapot.obj like the reference) and
+ * "composite" (BASELINE.json configs[4]: teapot + glass_spheres' spheres + reflective_floor; not a
+ * reference scene, frozen in rt_samples.cpp).  NULL on an unknown name or a parse error. */
+rt_sample*       rt_sample_create_obj(const char* name, const char* obj_text, uint64_t len, uint32_t width, uint32_t height);
 const rt_world*  rt_sample_world(const rt_sample* s);
 const rt_camera* rt_sample_camera(const rt_sample* s);
 void             rt_sample_destroy(rt_sample* s);

@@ -143,6 +143,7 @@ _SIGNATURES = [
     ("rt_obj_to_group", C.c_int, [C.c_void_p, C.c_int, P(P(st.Group))]),
     ("rt_obj_free", None, [C.c_void_p]),
     ("rt_sample_create", C.c_void_p, [C.c_char_p, u32, u32]),
+    ("rt_sample_create_obj", C.c_void_p, [C.c_char_p, C.c_char_p, C.c_uint64, u32, u32]),
     ("rt_sample_world", P(st.World), [C.c_void_p]),
     ("rt_sample_camera", P(st.Camera), [C.c_void_p]),
     ("rt_sample_destroy", None, [C.c_void_p]),
@@ -186,10 +187,14 @@ def fptr(a):
 class Sample:
     """One of the reference's sample scenes (samples/<name>.zig) built by the C++ mirror."""
 
-    def __init__(self, name, width=0, height=0):
+    def __init__(self, name, width=0, height=0, obj_text=None):
         L = lib()
         self.name = name
-        self.handle = L.rt_sample_create(name.encode(), width, height)
+        if obj_text is not None:  # "teapot" / "composite": the scenes built around an OBJ mesh
+            data = obj_text.encode() if isinstance(obj_text, str) else obj_text
+            self.handle = L.rt_sample_create_obj(name.encode(), data, len(data), width, height)
+        else:
+            self.handle = L.rt_sample_create(name.encode(), width, height)
         if not self.handle:
             raise KeyError(name)
         self.world = L.rt_sample_world(self.handle).contents
@@ -239,32 +244,10 @@ def teapot_scene(obj_text, width=256, height=256, extra=None):
 
 
 def composite_scene(obj_text, width=7680, height=4320):
-    """The scaled stress scene of BASELINE.json configs[4] — NOT a reference scene; frozen here:
-    the teapot group (samples/teapot.zig) standing on reflective_floor's checkered mirror plane,
-    glass_spheres' outer/inner glass pair to its right, reflective_floor's red sphere to its
-    left, teapot.zig's camera, light at (-5, 10, -10)."""
-    import math
-
-    def moved(shape, x, y, z):
-        out = st.Sphere(shape.common_attrs)
-        m = out.common_attrs.transform.to_numpy().copy()
-        t = np.eye(4, dtype=np.float32)
-        t[:3, 3] = [x, y, z]
-        mm = st.Mat4()
-        lib().rt_mat_mul(C.byref(st.Mat4.from_rows(t)), C.byref(st.Mat4.from_rows(m)), C.byref(mm))
-        out.common_attrs.transform = mm
-        return out
-
-    glass = Sample("glass_spheres")
-    floor = Sample("reflective_floor")
-    spheres = [moved(glass.world.spheres[0], 4.2, 1.0, -1.5), moved(glass.world.spheres[1], 4.2, 1.0, -1.5),
-               moved(floor.world.spheres[0], -4.0, 0.0, -2.0)]
-    obj = ObjFile(obj_text, bound=True)
-    world, keep = st.make_world([-5, 10, -10, 1], [1, 1, 1], groups=[obj.group], spheres=spheres,
-                                planes=[floor.world.planes[0]])
-    cam = camera(width, height, float(np.float32(math.pi / 3.0)), (0, 3, -10, 1), (0, 0, 0, 1), (0, 1, 0, 0))
-    keep += [obj, glass, floor]
-    return world, cam, keep
+    """BASELINE.json configs[4]'s scaled stress scene (frozen in host/rt_samples.cpp).
+    Returns (world, camera, keepalive) like teapot_scene."""
+    s = Sample("composite", width, height, obj_text=obj_text)
+    return s.world, s.camera, [s]
 
 
 SAMPLES = ["sphere_world", "glass_spheres", "fresnel", "cylinder_world", "cone", "cube", "reflective_floor",

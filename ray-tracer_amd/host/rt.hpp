@@ -18,6 +18,7 @@
 #pragma once
 
 #include <array>
+#include <memory>
 #include <optional>
 #include <ostream>
 #include <stdexcept>
@@ -150,6 +151,21 @@ struct GroupView {
     std::vector<Group> keep;  // optional: groups this view owns
     const rt_group* build(const std::vector<Group>& groups);
 };
+
+// src/obj_file.zig — rt.obj of src/main.zig:5.
+namespace obj {
+struct ParserError : std::runtime_error {  // src/obj_file.zig:25-27 (+ the number / index failures)
+    int code;                              // RT_OBJ_*
+    ParserError(int c, const char* what) : std::runtime_error(what), code(c) {}
+};
+struct ObjFile {
+    std::shared_ptr<rt_obj> handle;
+    Group toShapeGroup() const;  // :45-62 — caller owns the group, bound() is the caller's call
+    uint32_t vertexCount() const { return rt_obj_vertex_count(handle.get()); }
+    uint32_t faceCount() const { return rt_obj_face_count(handle.get()); }
+};
+ObjFile parseObjFile(const std::string& text);  // :77-147; throws ParserError
+}  // namespace obj
 
 // src/world.zig:22-36
 struct World {

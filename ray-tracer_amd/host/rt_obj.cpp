@@ -69,7 +69,35 @@ bool parse_index(const std::string& s, size_t& out) {  // std.fmt.parseInt(usize
     return true;
 }
 
+Group shape_group_of(const rt_obj& o) {  // toShapeGroup, :45-62
+    Group g = Group::init(mat::identity());
+    g.triangles = o.faces;
+    for (const auto& faces : o.group_faces) {
+        if (faces.empty()) continue;
+        Group sub = Group::init(mat::identity());
+        sub.triangles = faces;
+        g.subgroups.push_back(std::move(sub));
+    }
+    return g;
+}
+
 }  // namespace
+
+namespace rt {
+namespace obj {
+
+ObjFile parseObjFile(const std::string& text) {
+    rt_obj* h = nullptr;
+    const int rc = rt_obj_parse(text.data(), text.size(), &h);
+    if (rc != 0)
+        throw ParserError(rc, rc == RT_OBJ_INVALID_COMMAND ? "InvalidCommand" : rc == RT_OBJ_BAD_NUMBER ? "bad number" : "bad vertex index");
+    return ObjFile{std::shared_ptr<rt_obj>(h, rt_obj_free)};
+}
+
+Group ObjFile::toShapeGroup() const { return shape_group_of(*handle); }
+
+}  // namespace obj
+}  // namespace rt
 
 extern "C" {
 
@@ -153,14 +181,7 @@ uint32_t rt_obj_group_count(const rt_obj* o) {
 // toShapeGroup (:45-62) followed by Group.bound() when `bound` is set (samples/teapot.zig:19).
 int rt_obj_to_group(rt_obj* o, int bound, const rt_group** out) {
     if (!o || !out) return RTX_E_INVALID;
-    Group g = Group::init(mat::identity());
-    g.triangles = o->faces;
-    for (const auto& faces : o->group_faces) {
-        if (faces.empty()) continue;
-        Group sub = Group::init(mat::identity());
-        sub.triangles = faces;
-        g.subgroups.push_back(std::move(sub));
-    }
+    Group g = shape_group_of(*o);
     if (bound) g.bound();
     o->shape_group = std::move(g);
     o->view = GroupView();

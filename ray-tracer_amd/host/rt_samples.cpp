@@ -3,6 +3,8 @@
 // path that BASELINE.json's configs name.  samples/main.cpp renders them to PPM files like
 // the reference's sample programs do; tests fetch them through rt_sample_create().
 #include <cstring>
+#include <fstream>
+#include <sstream>
 #include <map>
 #include <memory>
 #include <string>
@@ -275,6 +277,38 @@ Built sphere_on_plane() {  // samples/sphere_on_plane.zig
     return b;
 }
 
+Built teapot(const std::string& obj_text) {  // samples/teapot.zig
+    Group obj_group = obj::parseObjFile(obj_text).toShapeGroup();
+    obj_group.bound();
+    Built b;
+    b.world.light = {point(0, 0, -10), {1, 1, 1}};
+    b.world.groups = {obj_group};
+    b.shot = {256, 256, (float)(pi / 3.0), point(0, 3, -10), point(0, 0, 0), vector(0, 1, 0)};
+    return b;
+}
+
+// The scaled stress scene of BASELINE.json configs[4] — NOT a reference scene; defined once
+// here and frozen: the teapot group standing on reflective_floor's checkered mirror plane,
+// glass_spheres' outer/inner glass pair to its right, reflective_floor's red sphere to its
+// left, teapot.zig's camera, light at (-5, 10, -10).
+Built composite(const std::string& obj_text) {
+    Built tea = teapot(obj_text), glass = glass_spheres(), floor = reflective_floor();
+    auto moved = [](Sphere s, float x, float y, float z) {
+        s.common_attrs.transform = mul(translation(x, y, z), mat::Matrix(s.common_attrs.transform));
+        return s;
+    };
+    Built b;
+    b.world.light = {point(-5, 10, -10), {1, 1, 1}};
+    b.world.spheres = {moved(glass.world.spheres[0], 4.2f, 1.0f, -1.5f), moved(glass.world.spheres[1], 4.2f, 1.0f, -1.5f),
+                       moved(floor.world.spheres[0], -4.0f, 0.0f, -2.0f)};
+    b.world.planes = {floor.world.planes[0]};
+    b.world.groups = tea.world.groups;
+    b.shot = tea.shot;
+    b.shot.width = 7680;
+    b.shot.height = 4320;
+    return b;
+}
+
 using Builder = Built (*)();
 const std::map<std::string, Builder>& builders() {
     static const std::map<std::string, Builder> m = {
@@ -297,11 +331,35 @@ struct rt_sample {
 
 extern "C" {
 
+static rt_sample* finish(Built&& b, uint32_t width, uint32_t height);
+
 rt_sample* rt_sample_create(const char* name, uint32_t width, uint32_t height) {
     if (!name) return nullptr;
+    if (!std::strcmp(name, "teapot")) {  // like samples/teapot.zig:7: "teapot.obj" in the working directory
+        std::ifstream f("teapot.obj", std::ios::binary);
+        if (!f) return nullptr;
+        std::stringstream text;
+        text << f.rdbuf();
+        const std::string t = text.str();
+        return rt_sample_create_obj(name, t.data(), t.size(), width, height);
+    }
     auto it = builders().find(name);
     if (it == builders().end()) return nullptr;
-    Built b = it->second();
+    return finish(it->second(), width, height);
+}
+
+rt_sample* rt_sample_create_obj(const char* name, const char* obj_text, uint64_t len, uint32_t width, uint32_t height) {
+    if (!name || !obj_text) return nullptr;
+    try {
+        const std::string text(obj_text, (size_t)len);
+        if (!std::strcmp(name, "teapot")) return finish(teapot(text), width, height);
+        if (!std::strcmp(name, "composite")) return finish(composite(text), width, height);
+    } catch (const obj::ParserError&) {
+    }
+    return nullptr;
+}
+
+static rt_sample* finish(Built&& b, uint32_t width, uint32_t height) {
     rt_sample* s = new rt_sample();
     s->world = std::move(b.world);
     s->view = s->world.view(s->groups);

@@ -12,6 +12,7 @@ import pytest
 
 rta = importlib.import_module("ray-tracer_amd")
 st = rta.st
+import scene_util as su  # noqa: E402
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 TRI = "v -1 1 0\nv -1 0 0\nv 1 0 0\nv 1 1 0\n\nf 1 2 3\nf 1 3 4\n"
@@ -95,3 +96,46 @@ def test_teapot_scene_flattens_in_insertion_order():
     assert d.n_nodes == 1 + 1 + 4 and d.n_shapes == 1568
     assert d.nodes[1].has_bounds == 1 and d.nodes[1].n_shapes == 0 and d.nodes[1].skip == 6
     assert all(d.nodes[i].has_bounds == 0 for i in range(2, 6))
+
+
+def test_cpp_teapot_sample_equals_the_assembled_scene(tmp_path, monkeypatch):
+    # samples/teapot.zig through the C++ mirror (rt::obj::parseObjFile -> toShapeGroup -> bound)
+    text = open(os.path.join(ROOT, "samples", "teapot.obj")).read()
+    world, cam, keep = rta.teapot_scene(text, 64, 48)
+    s = rta.Sample("teapot", 64, 48, obj_text=text)
+    assert su.world_bytes(s.world) == su.world_bytes(world)
+    assert bytes(s.camera) == bytes(cam)
+    # like the reference's program, the plain name reads ./teapot.obj
+    with pytest.raises(KeyError):
+        monkeypatch.chdir(tmp_path)
+        rta.Sample("teapot", 64, 48)
+    (tmp_path / "teapot.obj").write_text(text)
+    s2 = rta.Sample("teapot", 64, 48)
+    assert su.world_bytes(s2.world) == su.world_bytes(world)
+    shipped = rta.Sample("teapot", obj_text=text)
+    assert (shipped.camera.horizontal_size, shipped.camera.vertical_size) == (256, 256)
+
+
+def test_cpp_sample_rejects_bad_obj_and_unknown_names():
+    with pytest.raises(KeyError):
+        rta.Sample("teapot", obj_text="v 1 2\n")
+    with pytest.raises(KeyError):
+        rta.Sample("no_such_scene", obj_text="v 1 2 3\n")
+
+
+def test_composite_scene_is_frozen():
+    # BASELINE.json configs[4]: teapot group + glass pair + red sphere + mirror floor
+    text = open(os.path.join(ROOT, "samples", "teapot.obj")).read()
+    world, cam, keep = rta.composite_scene(text, 160, 90)
+    assert (world.n_spheres, world.n_planes, world.n_groups) == (3, 1, 1)
+    assert (cam.horizontal_size, cam.vertical_size) == (160, 90)
+    assert list(world.light_position) == [-5, 10, -10, 1]
+    glass = rta.Sample("glass_spheres")
+    t = world.spheres[1].common_attrs.transform.to_numpy()
+    assert np.array_equal(t, np.array([[0.5, 0, 0, 4.2], [0, 0.5, 0, 1.0], [0, 0, 0.5, -1.5], [0, 0, 0, 1]], dtype=np.float32))
+    assert bytes(world.spheres[0].common_attrs.material) == bytes(glass.world.spheres[0].common_attrs.material)
+    assert world.planes[0].common_attrs.material.reflective == np.float32(0.25)
+    d = rta.FlatScene(world).desc
+    assert d.n_shapes == 4 + 1568
+    default = rta.composite_scene(text, 0, 0)[1]
+    assert (default.horizontal_size, default.vertical_size) == (7680, 4320)
