@@ -18,7 +18,7 @@ import numpy as np
 from . import scene_types as st
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libraytracer_amd.so")
+LIB_PATH = os.environ.get("RTX_LIB") or os.path.join(HERE, "libraytracer_amd.so")  # RTX_LIB: A/B builds in experiments
 
 f32 = C.c_float
 u32 = C.c_uint32

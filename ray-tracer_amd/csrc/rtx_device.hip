@@ -761,8 +761,14 @@ struct LdsScene {
 // One ray-tree level.  GEN: level-0 rays come from the camera (rayForPixel,
 // src/camera.zig:70-82) instead of the queue.  TRACK: keep the n1 predecessor.  LDS: the
 // scene tables fit in LDS (p.lds_bytes of dynamic shared memory).
+// Register budget: 5 waves per SIMD (<= 96 VGPRs).  Measured on configs[1] (with
+// -fno-slp-vectorize, see the Makefile): 4 waves 1.47 ms/step, 5 waves 1.39, 6 waves (spills)
+// 1.41, 8 waves (spills) 1.62.
+#ifndef RTX_WAVES_PER_EU
+#define RTX_WAVES_PER_EU 5
+#endif
 template <bool GEN, bool TRACK, bool LDS>
-__global__ __launch_bounds__(256) void k_trace_shade(const Params p, const uint32_t level) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RTX_WAVES_PER_EU, RTX_WAVES_PER_EU))) void k_trace_shade(const Params p, const uint32_t level) {
     extern __shared__ uint4 lds_raw[];
     LdsScene tab{p.shapes, p.materials, p.patterns};
     if (LDS) {
@@ -1057,7 +1063,8 @@ struct rtx_scene {
     rtx_material* d_materials = nullptr;
     rtx_pattern* d_patterns = nullptr;
     uint32_t n_shapes = 0, n_nodes = 0, n_materials = 0, n_patterns = 0;
-    bool track_n1 = false;
+    bool track_n1 = false;   // some material is transparent: n1/n2 matter
+    bool can_spawn = false;  // some material is reflective or transparent: child rays exist
     float light_position[4];
     float light_intensity[3];
 
@@ -1076,6 +1083,7 @@ struct rtx_scene {
     size_t canvas_floats = 0;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     int num_cus = 256;
+    int resident_blocks[2] = {0, 0};  // k_trace_shade blocks per CU: [0] queue-fed, [1] ray-generating
     // profile = 1: pooled events bracketing each launch, pending until read back
     std::vector<hipEvent_t> prof_events;
     std::vector<int> prof_kind;  // per pair: 0 trace_shade, 1 combine
@@ -1174,6 +1182,19 @@ template <bool GEN>
 void launch_trace(const rtx_scene* s, const Params& p, uint32_t level, uint32_t blocks, hipStream_t st) {
     if (s->track_n1) launch_trace2<GEN, true>(p, level, blocks, st);
     else launch_trace2<GEN, false>(p, level, blocks, st);
+}
+
+// Resident 256-thread blocks per CU of the variant this scene launches (registers and LDS decide).
+template <bool GEN, bool TRACK>
+int resident_blocks2(uint32_t lds_bytes) {
+    int n = 0;
+    hipError_t e = lds_bytes ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_trace_shade<GEN, TRACK, true>, 256, lds_bytes)
+                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_trace_shade<GEN, TRACK, false>, 256, 0);
+    return (e == hipSuccess && n > 0) ? n : 4;
+}
+template <bool GEN>
+int resident_blocks(const rtx_scene* s, uint32_t lds_bytes) {
+    return s->track_n1 ? resident_blocks2<GEN, true>(lds_bytes) : resident_blocks2<GEN, false>(lds_bytes);
 }
 
 int validate_desc(const rtx_scene_desc* d) {
@@ -1277,14 +1298,20 @@ int run_levels(rtx_scene* s, Params& p, uint32_t pixels, uint32_t level0_items, 
     }
     // Every launch has a multiple of kShards waves (16 blocks of 4 waves), see k_trace_shade.
     constexpr uint32_t kBlockQuantum = kShards / 4u;
-    static const uint32_t blocks_per_cu = [] {  // tuning knob for experiments; default 4 = one resident round
+    // Persistent grid: one resident round of blocks (what fits the CUs at once), each wave
+    // grid-striding over its share.  RTX_BLOCKS_PER_CU overrides the occupancy query (experiments).
+    static const int bpc_override = [] {
         const char* e = getenv("RTX_BLOCKS_PER_CU");
-        const int v = e ? atoi(e) : 0;
-        return (uint32_t)(v > 0 ? v : 4);
+        return e ? atoi(e) : 0;
     }();
-    uint32_t max_blocks = ((uint32_t)s->num_cus * blocks_per_cu) / kBlockQuantum * kBlockQuantum;
-    if (max_blocks < kBlockQuantum) max_blocks = kBlockQuantum;
-    auto grid_for = [&](uint64_t items) {
+    if (s->resident_blocks[0] == 0) {
+        s->resident_blocks[0] = resident_blocks<false>(s, p.lds_bytes);
+        s->resident_blocks[1] = resident_blocks<true>(s, p.lds_bytes);
+    }
+    auto grid_for = [&](uint64_t items, bool gen) {
+        const uint32_t bpc = bpc_override > 0 ? (uint32_t)bpc_override : (uint32_t)s->resident_blocks[gen ? 1 : 0];
+        uint32_t max_blocks = ((uint32_t)s->num_cus * bpc) / kBlockQuantum * kBlockQuantum;
+        if (max_blocks < kBlockQuantum) max_blocks = kBlockQuantum;
         uint64_t blocks = (items + 255) / 256;
         blocks = (blocks + kBlockQuantum - 1) / kBlockQuantum * kBlockQuantum;
         if (blocks > max_blocks) blocks = max_blocks;
@@ -1301,21 +1328,24 @@ int run_levels(rtx_scene* s, Params& p, uint32_t pixels, uint32_t level0_items, 
         (void)hipEventRecord(s->prof_events[s->prof_used++], st);
         if (kind >= 0) s->prof_kind.push_back(kind);
     };
-    for (uint32_t level = 0; level <= p.depth; ++level) {
+    // A scene without a reflective or transparent material never spawns a child ray
+    // (src/world.zig:131,151): its deeper levels would be empty launches.
+    const uint32_t last_level = s->can_spawn ? p.depth : 0u;
+    for (uint32_t level = 0; level <= last_level; ++level) {
         // Level 0 knows its size; deeper levels read theirs on the device and grid-stride.
-        const uint32_t blocks = grid_for(level == 0 ? level0_items : ((uint64_t)pixels << level));
+        const uint32_t blocks = grid_for(level == 0 ? level0_items : ((uint64_t)pixels << level), GEN && level == 0);
         mark(0);
         if (level == 0) launch_trace<GEN>(s, p, level, blocks, st);
         else launch_trace<false>(s, p, level, blocks, st);
         mark(-1);
     }
-    for (int level = (int)p.depth - 1; level >= 0; --level) {
-        const uint32_t blocks = grid_for((uint64_t)pixels << level);
+    for (int level = (int)last_level - 1; level >= 0; --level) {
+        const uint32_t blocks = grid_for((uint64_t)pixels << level, false);
         mark(1);
         hipLaunchKernelGGL(k_combine, dim3(blocks), dim3(256), 0, st, p, (uint32_t)level);
         mark(-1);
     }
-    hipLaunchKernelGGL(k_accumulate, dim3(1), dim3(kShards), 0, st, s->d_counters, s->d_totals, level0_items ? pixels : 0u, p.depth,
+    hipLaunchKernelGGL(k_accumulate, dim3(1), dim3(kShards), 0, st, s->d_counters, s->d_totals, level0_items ? pixels : 0u, last_level,
                        first ? 1u : 0u);
     HIP_TRY(hipGetLastError());
     return RTX_OK;
@@ -1477,7 +1507,11 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out) {
     std::memcpy(s->light_position, desc->light_position, sizeof s->light_position);
     std::memcpy(s->light_intensity, desc->light_intensity, sizeof s->light_intensity);
     for (uint32_t i = 0; i < desc->n_shapes; ++i)
-        if (desc->materials[desc->shapes[i].material].transparency != 0.0f) s->track_n1 = true;
+    {
+        const rtx_material& m = desc->materials[desc->shapes[i].material];
+        if (m.transparency != 0.0f) s->track_n1 = true;
+        if (m.transparency != 0.0f || m.reflective != 0.0f) s->can_spawn = true;
+    }
 
     auto upload = [&](void** dst, const void* src, size_t bytes) -> hipError_t {
         hipError_t e = hipMalloc(dst, bytes ? bytes : 16);
