@@ -217,17 +217,20 @@ struct ClosestVisitor {
         c.pred_t = 0.0f;
         c.pred_idx = kNone;
     }
-    // Ties are decided on the insertion index explicitly (lowest wins for the hit, highest for
-    // the predecessor), so the result does not depend on the order shapes are visited in —
-    // the BVH visits triangles out of insertion order.
+    // Ties go to the lowest insertion index for the hit and to the highest for the predecessor.
+    // The world/group walk offers shapes in insertion order (ORDERED): a strict compare is
+    // enough there.  The BVH offers triangles in tree order, so it compares the index too.
+    template <bool ORDERED>
     __device__ __forceinline__ void hit(float t, uint32_t s) {
-        if (t >= 0.0f && (c.idx == kNone || t < c.t || (t == c.t && s < c.idx))) {
+        if (t >= 0.0f && (c.idx == kNone || t < c.t || (!ORDERED && t == c.t && s < c.idx))) {
             c.t = t;
             c.idx = s;
         }
     }
+    template <bool ORDERED>
     __device__ __forceinline__ void pred(float t, uint32_t s) {
-        if (TRACK && t < 0.0f && (c.pred_idx == kNone || t > c.pred_t || (t == c.pred_t && s > c.pred_idx))) {
+        if (TRACK && t < 0.0f &&
+            (c.pred_idx == kNone || (ORDERED ? t >= c.pred_t : (t > c.pred_t || (t == c.pred_t && s > c.pred_idx))))) {
             c.pred_t = t;
             c.pred_idx = s;
         }
@@ -245,9 +248,11 @@ struct ClosestVisitor {
 struct ShadowVisitor {
     float distance;
     bool found;
+    template <bool ORDERED>
     __device__ __forceinline__ void hit(float t, uint32_t) {
         if (t >= 0.0f && t < distance) found = true;
     }
+    template <bool ORDERED>
     __device__ __forceinline__ void pred(float, uint32_t) {}
     static constexpr bool kTrack = false;
     __device__ __forceinline__ bool done() const { return found; }
@@ -285,13 +290,28 @@ __device__ __forceinline__ bool bounds_hit(const RT_CONST rtx_node& n, V4 o, V4 
     return tmin <= tmax;
 }
 
-// Offer up to four roots of one shape.  For the predecessor, roots of the same shape with
-// exactly equal t cancel pairwise (they are equal Intersections in the container walk).
+// Offer the roots of one shape (insertion-ordered walk).  For the predecessor, roots of the same
+// shape with exactly equal t cancel pairwise (they are equal Intersections in the container walk).
+template <class V>
+__device__ __forceinline__ void offer1(V& v, uint32_t s, bool n1_visible, float t) {
+    v.template hit<true>(t, s);
+    if (V::kTrack && n1_visible) v.template pred<true>(t, s);
+}
+template <class V>
+__device__ __forceinline__ void offer2(V& v, uint32_t s, bool n1_visible, float t0, float t1) {
+    v.template hit<true>(t0, s);
+    v.template hit<true>(t1, s);
+    if (V::kTrack && n1_visible && t0 != t1) {  // equal roots cancel each other
+        v.template pred<true>(t0, s);
+        v.template pred<true>(t1, s);
+    }
+}
+// Up to four roots with validity flags (cylinder / cone: two walls, two caps).
 template <class V>
 __device__ __forceinline__ void offer_roots(V& v, uint32_t s, bool n1_visible, const float* t, const bool* ok) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-        if (ok[i]) v.hit(t[i], s);
+        if (ok[i]) v.template hit<true>(t[i], s);
     if (V::kTrack && n1_visible) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -300,7 +320,7 @@ __device__ __forceinline__ void offer_roots(V& v, uint32_t s, bool n1_visible, c
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 if (ok[j] && t[j] == t[i]) ++same;
-            if (same & 1) v.pred(t[i], s);
+            if (same & 1) v.template pred<true>(t[i], s);
         }
     }
 }
@@ -339,8 +359,6 @@ __device__ __forceinline__ void intersect_shape(V& v, const RT_CONST rtx_shape& 
         rd = mul_mat(inv, d);
     }
     const bool n1_visible = !(sh.flags & RTX_SHAPE_N1_INVISIBLE);
-    float t[4];
-    bool ok[4] = {false, false, false, false};
 
     switch (sh.type) {
     case RTX_SPHERE: {  // src/sphere.zig:11-54
@@ -351,18 +369,13 @@ __device__ __forceinline__ void intersect_shape(V& v, const RT_CONST rtx_shape& 
         const float discriminant = b * b - 4.0f * a * c;
         if (discriminant >= 0.0f) {
             const float sq = sqrtf(discriminant);
-            t[0] = (-b - sq) / (2.0f * a);
-            t[1] = (-b + sq) / (2.0f * a);
-            ok[0] = ok[1] = true;
+            offer2(v, s, n1_visible, (-b - sq) / (2.0f * a), (-b + sq) / (2.0f * a));
         }
-        break;
+        return;
     }
     case RTX_PLANE: {  // src/plane.zig:13-28
-        if (!(fabsf(rd.y) < kEpsilon)) {
-            t[0] = -ro.y / rd.y;
-            ok[0] = true;
-        }
-        break;
+        if (!(fabsf(rd.y) < kEpsilon)) offer1(v, s, n1_visible, -ro.y / rd.y);
+        return;
     }
     case RTX_CUBE: {  // src/cube.zig:11-26
         const TMinMax x = check_axis(-1.0f, 1.0f, ro.x, rd.x);
@@ -370,16 +383,14 @@ __device__ __forceinline__ void intersect_shape(V& v, const RT_CONST rtx_shape& 
         const TMinMax z = check_axis(-1.0f, 1.0f, ro.z, rd.z);
         const float tmin = fmaxf(x.tmin, fmaxf(y.tmin, z.tmin));
         const float tmax = fminf(x.tmax, fminf(y.tmax, z.tmax));
-        if (!(tmin > tmax)) {
-            t[0] = tmin;
-            t[1] = tmax;
-            ok[0] = ok[1] = true;
-        }
-        break;
+        if (!(tmin > tmax)) offer2(v, s, n1_visible, tmin, tmax);
+        return;
     }
     case RTX_CYLINDER:  // src/cylinder.zig:14-71
     case RTX_CONE: {    // src/cone.zig:14-82
         const bool cone = sh.type == RTX_CONE;
+        float t[4];
+        bool ok[4] = {false, false, false, false};
         float a, b, c;
         if (cone) {
             a = rd.x * rd.x - rd.y * rd.y + rd.z * rd.z;
@@ -444,7 +455,8 @@ __device__ __forceinline__ void intersect_shape(V& v, const RT_CONST rtx_shape& 
                 }
             }
         }
-        break;
+        offer_roots(v, s, n1_visible, t, ok);
+        return;
     }
     default: {  // RTX_TRIANGLE
         float p0[3], e0[3], e1[3];
@@ -454,11 +466,11 @@ __device__ __forceinline__ void intersect_shape(V& v, const RT_CONST rtx_shape& 
             e0[k] = sh.e0[k];
             e1[k] = sh.e1[k];
         }
-        ok[0] = triangle_root(ro, rd, p0, e0, e1, t[0]);
-        break;
+        float tt;
+        if (triangle_root(ro, rd, p0, e0, e1, tt)) offer1(v, s, n1_visible, tt);
+        return;
     }
     }
-    offer_roots(v, s, n1_visible, t, ok);
 }
 
 // Per-lane walk of one triangle BVH (threaded pre-order, no stack).  Only culling happens
@@ -502,8 +514,8 @@ __device__ __forceinline__ void traverse_bvh(V& v, const Params& p, uint32_t roo
                 const float p0[3] = {q0.x, q0.y, q0.z}, e0[3] = {q1.x, q1.y, q1.z}, e1[3] = {q2.x, q2.y, q2.z};
                 float t;
                 if (triangle_root(ro, rd, p0, e0, e1, t)) {
-                    v.hit(t, shape);
-                    if (V::kTrack && !(flags & RTX_SHAPE_N1_INVISIBLE)) v.pred(t, shape);
+                    v.template hit<false>(t, shape);
+                    if (V::kTrack && !(flags & RTX_SHAPE_N1_INVISIBLE)) v.template pred<false>(t, shape);
                 }
             }
             n = skip;
