@@ -144,7 +144,8 @@ typedef struct rtx_opts {
     uint32_t compact_rows;
     uint32_t profile;      /* 1: time each kernel class with HIP events (adds syncs) */
     uint32_t no_bvh;       /* 1: test every triangle of a group linearly (A/B check of the triangle BVH) */
-    uint32_t reserved;
+    uint32_t full_w;       /* 1: keep the w lane of every tuple operation even where the scene makes it an exact
+                              0 / 1 (A/B check of the canonical-w kernels; same canvas, slower) */
 } rtx_opts;
 
 typedef struct rtx_stats {

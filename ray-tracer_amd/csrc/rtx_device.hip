@@ -122,6 +122,7 @@ struct Params {
     uint32_t n_patterns;
     uint32_t lds_bytes;  // > 0: the scene tables are staged in this much dynamic LDS
     uint32_t track_n1;  // scene has a transparent material: track the n1 predecessor
+    uint32_t canon;     // this frame runs the canonical-w kernels (ray records are 32 bytes)
     uint32_t depth;
     float light_position[4];
     float light_intensity[3];
@@ -157,15 +158,33 @@ __device__ __forceinline__ V4 v4(float x, float y, float z, float w) { return V4
 __device__ __forceinline__ V4 add(V4 a, V4 b) { return v4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ V4 sub(V4 a, V4 b) { return v4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 __device__ __forceinline__ V4 muls(V4 a, float s) { return v4(a.x * s, a.y * s, a.z * s, a.w * s); }
-__device__ __forceinline__ V4 divs(V4 a, float s) { return v4(a.x / s, a.y / s, a.z / s, a.w / s); }
 __device__ __forceinline__ V4 neg(V4 a) { return v4(-a.x, -a.y, -a.z, -a.w); }
 
+// The template flag C ("canonical") marks kernels for scenes in which every point carries
+// w == 1 and every vector w == 0 exactly: all shape inverses, the camera inverse and the light
+// end in (0, 0, 0, 1) and no cube is translated (the reference normalises a cube normal with
+// its w lane, src/cube.zig:28-44, so a translated cube leaks a non-zero w into its rays).
+// There the w lanes of the reference's four-lane arithmetic only ever add an exact zero
+// (u.w * v.w with one factor 0) or multiply by an exact one, so they are left out: the results
+// are the same f32 values (a zero may differ in sign, which no consumer here can observe).
+// The host picks C per frame (scene_is_canonical, camera_is_canonical); C == false keeps every lane.
+
 // tup.dot — four lanes, left to right (src/tuple.zig:38-40)
-__device__ __forceinline__ float dot(V4 u, V4 v) { return u.x * v.x + u.y * v.y + u.z * v.z + u.w * v.w; }
-__device__ __forceinline__ float magnitude(V4 v) { return sqrtf(dot(v, v)); }          // tuple.zig:50-52
-__device__ __forceinline__ V4 normalize(V4 v) { return divs(v, magnitude(v)); }        // tuple.zig:54-56
-__device__ __forceinline__ V4 reflect(V4 incident, V4 normal) {                        // tuple.zig:58-77
-    return sub(incident, muls(muls(normal, dot(incident, normal)), 2.0f));
+template <bool C>
+__device__ __forceinline__ float dot(V4 u, V4 v) {
+    const float s = u.x * v.x + u.y * v.y + u.z * v.z;
+    return C ? s : s + u.w * v.w;
+}
+template <bool C>
+__device__ __forceinline__ float magnitude(V4 v) { return sqrtf(dot<C>(v, v)); }  // tuple.zig:50-52
+template <bool C>
+__device__ __forceinline__ V4 normalize(V4 v) {                                   // tuple.zig:54-56
+    const float m = magnitude<C>(v);
+    return v4(v.x / m, v.y / m, v.z / m, C ? 0.0f : v.w / m);
+}
+template <bool C>
+__device__ __forceinline__ V4 reflect(V4 incident, V4 normal) {                   // tuple.zig:58-77
+    return sub(incident, muls(muls(normal, dot<C>(incident, normal)), 2.0f));
 }
 
 // mat.mulTuple (src/matrix.zig:62-64) with a row-major 16-float matrix.
@@ -174,8 +193,24 @@ __device__ __forceinline__ V4 mul_mat(const float* m, V4 b) {
               m[8] * b.x + m[9] * b.y + m[10] * b.z + m[11] * b.w,
               m[12] * b.x + m[13] * b.y + m[14] * b.z + m[15] * b.w);
 }
-// mat.mul(mat.transpose(m), b) (src/matrix.zig:74-87 then :62-64)
+// The same for a point (w == 1 when C) and for a vector (w == 0 when C).
+template <bool C>
+__device__ __forceinline__ V4 mul_point(const float* m, V4 b) {
+    if (!C) return mul_mat(m, b);
+    return v4(m[0] * b.x + m[1] * b.y + m[2] * b.z + m[3], m[4] * b.x + m[5] * b.y + m[6] * b.z + m[7],
+              m[8] * b.x + m[9] * b.y + m[10] * b.z + m[11], 1.0f);
+}
+template <bool C>
+__device__ __forceinline__ V4 mul_dir(const float* m, V4 b) {
+    if (!C) return mul_mat(m, b);
+    return v4(m[0] * b.x + m[1] * b.y + m[2] * b.z, m[4] * b.x + m[5] * b.y + m[6] * b.z,
+              m[8] * b.x + m[9] * b.y + m[10] * b.z, 0.0f);
+}
+// mat.mul(mat.transpose(m), b) (src/matrix.zig:74-87 then :62-64); b is a normal (w == 0 when C).
+template <bool C>
 __device__ __forceinline__ V4 mul_mat_t(const float* m, V4 b) {
+    if (C) return v4(m[0] * b.x + m[4] * b.y + m[8] * b.z, m[1] * b.x + m[5] * b.y + m[9] * b.z,
+                     m[2] * b.x + m[6] * b.y + m[10] * b.z, 0.0f);
     return v4(m[0] * b.x + m[4] * b.y + m[8] * b.z + m[12] * b.w, m[1] * b.x + m[5] * b.y + m[9] * b.z + m[13] * b.w,
               m[2] * b.x + m[6] * b.y + m[10] * b.z + m[14] * b.w,
               m[3] * b.x + m[7] * b.y + m[11] * b.z + m[15] * b.w);
@@ -348,24 +383,24 @@ __device__ __forceinline__ bool triangle_root(V4 ro, V4 rd, const float* p0, con
 // Shape.intersect for every shape type; `sh` is wave-uniform (scalar loads), the ray is
 // per lane.  o/d are the world-space ray; the object-space ray is r.transform(inverse)
 // (src/ray.zig:13-18) with all four lanes kept.
-template <class V>
+template <bool C, class V>
 __device__ __forceinline__ void intersect_shape(V& v, const RT_CONST rtx_shape& sh, uint32_t s, V4 o, V4 d) {
     V4 ro = o, rd = d;
     if (!(sh.flags & kShapeIdentity)) {  // x * identity is x (up to the sign of a zero): skip it
         float inv[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) inv[k] = sh.inverse[k];
-        ro = mul_mat(inv, o);
-        rd = mul_mat(inv, d);
+        ro = mul_point<C>(inv, o);
+        rd = mul_dir<C>(inv, d);
     }
     const bool n1_visible = !(sh.flags & RTX_SHAPE_N1_INVISIBLE);
 
     switch (sh.type) {
     case RTX_SPHERE: {  // src/sphere.zig:11-54
         const V4 sphere_to_ray = sub(ro, v4(0.0f, 0.0f, 0.0f, 1.0f));
-        const float a = dot(rd, rd);
-        const float b = 2.0f * dot(rd, sphere_to_ray);
-        const float c = dot(sphere_to_ray, sphere_to_ray) - 1.0f;
+        const float a = dot<C>(rd, rd);
+        const float b = 2.0f * dot<C>(rd, sphere_to_ray);
+        const float c = dot<C>(sphere_to_ray, sphere_to_ray) - 1.0f;
         const float discriminant = b * b - 4.0f * a * c;
         if (discriminant >= 0.0f) {
             const float sq = sqrtf(discriminant);
@@ -475,7 +510,7 @@ __device__ __forceinline__ void intersect_shape(V& v, const RT_CONST rtx_shape& 
 
 // Per-lane walk of one triangle BVH (threaded pre-order, no stack).  Only culling happens
 // here; every surviving triangle goes through the reference's test and the visitor.
-template <class V>
+template <bool C, class V>
 __device__ __forceinline__ void traverse_bvh(V& v, const Params& p, uint32_t root, V4 o, V4 d) {
     const float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
     const rtx_bvh::Node* nodes = p.bvh_nodes;
@@ -508,8 +543,8 @@ __device__ __forceinline__ void traverse_bvh(V& v, const Params& p, uint32_t roo
                 V4 ro = o, rd = d;
                 if (!(flags & kShapeIdentity)) {
                     const float* inv = p.shapes[shape].inverse;
-                    ro = mul_mat(inv, o);
-                    rd = mul_mat(inv, d);
+                    ro = mul_point<C>(inv, o);
+                    rd = mul_dir<C>(inv, d);
                 }
                 const float p0[3] = {q0.x, q0.y, q0.z}, e0[3] = {q1.x, q1.y, q1.z}, e1[3] = {q2.x, q2.y, q2.z};
                 float t;
@@ -530,7 +565,7 @@ __device__ __forceinline__ void traverse_bvh(V& v, const Params& p, uint32_t roo
 // through scalar loads); a lane whose ray failed a group's box is parked until the loop
 // leaves that group's subtree.  `lane_on` is false for padding lanes.  A node whose triangle
 // run has a BVH tests only its `n_linear` leading shapes linearly.
-template <class V>
+template <bool C, class V>
 __device__ __forceinline__ void traverse(V& v, const Params& p, V4 o, V4 d, bool lane_on) {
     uint32_t parked_until = lane_on ? 0u : kNone;  // node index at which this lane wakes up
     const RT_CONST rtx_node* nodes = as_const(p.nodes);
@@ -547,21 +582,22 @@ __device__ __forceinline__ void traverse(V& v, const Params& p, V4 o, V4 d, bool
         const uint32_t first = node.first_shape;
         const uint32_t last = first + (bvh_root ? node.reserved[1] : node.n_shapes);
         for (uint32_t s = first; s < last; ++s) {
-            if (active) intersect_shape(v, shapes[s], s, o, d);
+            if (active) intersect_shape<C>(v, shapes[s], s, o, d);
         }
-        if (bvh_root && active) traverse_bvh(v, p, bvh_root - 1u, o, d);
+        if (bvh_root && active) traverse_bvh<C>(v, p, bvh_root - 1u, o, d);
     }
 }
 
 // ------------------------------------------------------------------------ shading
 
 // Shape.normalAt for the hit shape (per-lane record).
+template <bool C>
 __device__ __forceinline__ V4 normal_at(const rtx_shape& sh, V4 world_point) {
     const float* inv = sh.inverse;
     V4 object_normal;
     switch (sh.type) {
     case RTX_SPHERE: {  // src/sphere.zig:56-82
-        const V4 object_point = mul_mat(inv, world_point);
+        const V4 object_point = mul_point<C>(inv, world_point);
         object_normal = sub(object_point, v4(0.0f, 0.0f, 0.0f, 1.0f));
         break;
     }
@@ -569,16 +605,16 @@ __device__ __forceinline__ V4 normal_at(const rtx_shape& sh, V4 world_point) {
         object_normal = v4(0.0f, 1.0f, 0.0f, 0.0f);
         break;
     case RTX_CUBE: {  // src/cube.zig:28-44 — w is NOT reset before normalising
-        const V4 object_point = mul_mat(inv, world_point);
+        const V4 object_point = mul_point<C>(inv, world_point);
         const float x = fabsf(object_point.x), y = fabsf(object_point.y), z = fabsf(object_point.z);
         const float maxc = fmaxf(x, fmaxf(y, z));
         if (maxc == x) object_normal = v4(object_point.x, 0.0f, 0.0f, 0.0f);
         else if (maxc == y) object_normal = v4(0.0f, object_point.y, 0.0f, 0.0f);
         else object_normal = v4(0.0f, 0.0f, object_point.z, 0.0f);
-        return normalize(mul_mat_t(inv, object_normal));
+        return normalize<C>(mul_mat_t<C>(inv, object_normal));
     }
     case RTX_CYLINDER: {  // src/cylinder.zig:73-92
-        const V4 object_point = mul_mat(inv, world_point);
+        const V4 object_point = mul_point<C>(inv, world_point);
         const float distance = object_point.x * object_point.x + object_point.z * object_point.z;
         if (distance < 1.0f && object_point.y >= sh.maximum - kEpsilon) object_normal = v4(0.0f, 1.0f, 0.0f, 0.0f);
         else if (distance < 1.0f && object_point.y <= sh.minimum + kEpsilon) object_normal = v4(0.0f, -1.0f, 0.0f, 0.0f);
@@ -586,7 +622,7 @@ __device__ __forceinline__ V4 normal_at(const rtx_shape& sh, V4 world_point) {
         break;
     }
     case RTX_CONE: {  // src/cone.zig:84-105
-        const V4 object_point = mul_mat(inv, world_point);
+        const V4 object_point = mul_point<C>(inv, world_point);
         const float distance = object_point.x * object_point.x + object_point.z * object_point.z;
         if (distance < sh.maximum * sh.maximum && object_point.y >= sh.maximum - kEpsilon) {
             object_normal = v4(0.0f, 1.0f, 0.0f, 0.0f);
@@ -602,9 +638,9 @@ __device__ __forceinline__ V4 normal_at(const rtx_shape& sh, V4 world_point) {
         object_normal = v4(sh.normal[0], sh.normal[1], sh.normal[2], sh.normal[3]);
         break;
     }
-    V4 world_normal = mul_mat_t(inv, object_normal);
+    V4 world_normal = mul_mat_t<C>(inv, object_normal);
     world_normal.w = 0.0f;
-    return normalize(world_normal);
+    return normalize<C>(world_normal);
 }
 
 // @mod(x, 2) == 0 under floored modulo  <=>  fmodf(x, 2) is +-0.
@@ -615,9 +651,10 @@ struct Color {
 };
 
 // Pattern.atShape (src/pattern.zig:23-51)
+template <bool C>
 __device__ __forceinline__ Color pattern_at_shape(const rtx_pattern& pat, const rtx_shape& sh, V4 world_point) {
-    const V4 object_point = mul_mat(sh.inverse, world_point);
-    const V4 pt = mul_mat(pat.inverse, object_point);
+    const V4 object_point = mul_point<C>(sh.inverse, world_point);
+    const V4 pt = mul_point<C>(pat.inverse, object_point);  // only x, y, z are read
     const Color a{pat.a[0], pat.a[1], pat.a[2]}, b{pat.b[0], pat.b[1], pat.b[2]};
     switch (pat.color_map) {
     case RT_PATTERN_STRIPE:
@@ -634,26 +671,27 @@ __device__ __forceinline__ Color pattern_at_shape(const rtx_pattern& pat, const 
 }
 
 // Material.lighting (src/material.zig:40-102)
+template <bool C>
 __device__ __forceinline__ Color lighting(const Params& p, const rtx_pattern* patterns, const rtx_material& m,
                                           const rtx_shape& sh, V4 point, V4 eye, V4 normal, bool in_shadow) {
     Color color;
-    if (m.pattern >= 0) color = pattern_at_shape(patterns[m.pattern], sh, point);
+    if (m.pattern >= 0) color = pattern_at_shape<C>(patterns[m.pattern], sh, point);
     else color = Color{m.color[0], m.color[1], m.color[2]};
 
     const Color li{p.light_intensity[0], p.light_intensity[1], p.light_intensity[2]};
     const Color effective{color.r * li.r, color.g * li.g, color.b * li.b};
     const V4 lp = v4(p.light_position[0], p.light_position[1], p.light_position[2], p.light_position[3]);
-    const V4 light_direction = normalize(sub(lp, point));
+    const V4 light_direction = normalize<C>(sub(lp, point));
     const Color ambient{effective.r * m.ambient, effective.g * m.ambient, effective.b * m.ambient};
     if (in_shadow) return ambient;
 
     Color diffuse{0.0f, 0.0f, 0.0f}, specular{0.0f, 0.0f, 0.0f};
-    const float cos_light_normal = dot(light_direction, normal);
+    const float cos_light_normal = dot<C>(light_direction, normal);
     if (!(cos_light_normal < 0.0f)) {
         diffuse = Color{effective.r * m.diffuse * cos_light_normal, effective.g * m.diffuse * cos_light_normal,
                         effective.b * m.diffuse * cos_light_normal};
-        const V4 refl = reflect(neg(light_direction), normal);
-        const float cos_reflect_eye = dot(refl, eye);
+        const V4 refl = reflect<C>(neg(light_direction), normal);
+        const float cos_reflect_eye = dot<C>(refl, eye);
         if (!(cos_reflect_eye <= 0.0f)) {
             const float factor = rt::zmath::pow_f32(cos_reflect_eye, m.shininess);
             specular = Color{li.r * m.specular * factor, li.g * m.specular * factor, li.b * m.specular * factor};
@@ -663,10 +701,11 @@ __device__ __forceinline__ Color lighting(const Params& p, const rtx_pattern* pa
 }
 
 // schlick (src/intersection.zig:161-180)
+template <bool C>
 __device__ __forceinline__ float schlick(float n1, float n2, V4 eye, V4 normal) {
     float r0 = (n1 - n2) / (n1 + n2);
     r0 *= r0;
-    float cosv = dot(eye, normal);
+    float cosv = dot<C>(eye, normal);
     if (n1 > n2) {
         const float n = n1 / n2;
         const float sin2_t = n * n * (1.0f - cosv * cosv);
@@ -772,14 +811,16 @@ struct LdsScene {
 
 // One ray-tree level.  GEN: level-0 rays come from the camera (rayForPixel,
 // src/camera.zig:70-82) instead of the queue.  TRACK: keep the n1 predecessor.  LDS: the
-// scene tables fit in LDS (p.lds_bytes of dynamic shared memory).
+// scene tables fit in LDS (p.lds_bytes of dynamic shared memory).  C: canonical w lanes (see
+// dot<C>); rays then travel as two float4 (origin.xyz + link, direction.xyz + weight = 32 B)
+// instead of origin, direction and a link/weight pair (40 B).
 // Register budget: 5 waves per SIMD (<= 96 VGPRs).  Measured on configs[1] (with
 // -fno-slp-vectorize, see the Makefile): 4 waves 1.47 ms/step, 5 waves 1.39, 6 waves (spills)
 // 1.41, 8 waves (spills) 1.62.
 #ifndef RTX_WAVES_PER_EU
 #define RTX_WAVES_PER_EU 5
 #endif
-template <bool GEN, bool TRACK, bool LDS>
+template <bool GEN, bool TRACK, bool LDS, bool C>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RTX_WAVES_PER_EU, RTX_WAVES_PER_EU))) void k_trace_shade(const Params p, const uint32_t level) {
     extern __shared__ uint4 lds_raw[];
     LdsScene tab{p.shapes, p.materials, p.patterns};
@@ -851,16 +892,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RTX_WAVES_P
             const float world_y = p.half_height - y_offset;
             const V4 pixel = mul_mat(p.cam_inv, v4(world_x, world_y, -1.0f, 1.0f));
             o = mul_mat(p.cam_inv, v4(0.0f, 0.0f, 0.0f, 1.0f));
-            d = normalize(sub(pixel, o));
+            d = normalize<C>(sub(pixel, o));
             link = (p.compact_rows ? lrow : py) * p.width + px;
         } else if (on) {
             const float4 qo4 = p.q_org[qi][in_base + i];
             const float4 qd4 = p.q_dir[qi][in_base + i];
-            const uint2 ql = p.q_link[qi][in_base + i];
-            o = v4(qo4.x, qo4.y, qo4.z, qo4.w);
-            d = v4(qd4.x, qd4.y, qd4.z, qd4.w);
-            link = ql.x;
-            weight = __uint_as_float(ql.y);
+            if (C) {
+                o = v4(qo4.x, qo4.y, qo4.z, 1.0f);
+                d = v4(qd4.x, qd4.y, qd4.z, 0.0f);
+                link = __float_as_uint(qo4.w);
+                weight = qd4.w;
+            } else {
+                const uint2 ql = p.q_link[qi][in_base + i];
+                o = v4(qo4.x, qo4.y, qo4.z, qo4.w);
+                d = v4(qd4.x, qd4.y, qd4.z, qd4.w);
+                link = ql.x;
+                weight = __uint_as_float(ql.y);
+            }
         } else {
             o = v4(0.0f, 0.0f, 0.0f, 1.0f);
             d = v4(0.0f, 0.0f, 1.0f, 0.0f);
@@ -870,7 +918,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RTX_WAVES_P
         // colorAtInternal: world.intersect + hit (src/world.zig:85-95)
         ClosestVisitor<TRACK> cv;
         cv.init();
-        traverse(cv, p, o, d, on);
+        traverse<C>(cv, p, o, d, on);
         const bool is_hit = on && cv.c.idx != kNone;
         DIAG_PHASE(1);  // closest-hit traversal
 
@@ -882,16 +930,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RTX_WAVES_P
             ++local_hits;
             const rtx_shape& sh = tab.shapes[cv.c.idx];
             point = add(o, muls(d, cv.c.t));  // ray.position, src/ray.zig:9-11
-            normal = normal_at(sh, point);
-            if (dot(normal, neg(d)) < 0.0f) normal = neg(normal);
+            normal = normal_at<C>(sh, point);
+            if (dot<C>(normal, neg(d)) < 0.0f) normal = neg(normal);
             // n1 / n2 (src/intersection.zig:92-159, see Closest above)
             if (TRACK && cv.c.pred_idx != kNone) n1 = tab.materials[tab.shapes[cv.c.pred_idx].material].refractive_index;
             n2 = tab.materials[sh.material].refractive_index;
             over_point = add(point, muls(normal, p.over_eps));
             const V4 lp = v4(p.light_position[0], p.light_position[1], p.light_position[2], p.light_position[3]);
             const V4 to_light = sub(lp, over_point);
-            shadow_distance = magnitude(to_light);
-            shadow_dir = normalize(to_light);
+            shadow_distance = magnitude<C>(to_light);
+            shadow_dir = normalize<C>(to_light);
         }
 
         DIAG_PHASE(2);  // prepareComputations + shadow-ray set-up
@@ -900,7 +948,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RTX_WAVES_P
         ShadowVisitor sv;
         sv.distance = shadow_distance;
         sv.found = false;
-        traverse(sv, p, over_point, shadow_dir, is_hit);
+        traverse<C>(sv, p, over_point, shadow_dir, is_hit);
         DIAG_PHASE(3);  // shadow traversal
 
         bool spawn_reflect = false, spawn_refract = false, use_schlick = false;
@@ -911,19 +959,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RTX_WAVES_P
             const rtx_shape& sh = tab.shapes[cv.c.idx];
             const rtx_material& m = tab.materials[sh.material];
             const V4 eye = neg(d);
-            reflectv = reflect(d, normal);
+            reflectv = reflect<C>(d, normal);
             reflective = m.reflective;
             transparency = m.transparency;
             local_patterned += m.pattern >= 0 ? 1u : 0u;
             local_transparent += m.transparency != 0.0f ? 1u : 0u;
             // shadeHitInternal (src/world.zig:54-79): Phong is evaluated at over_point.
-            surface = lighting(p, tab.patterns, m, sh, over_point, eye, normal, sv.found);
+            surface = lighting<C>(p, tab.patterns, m, sh, over_point, eye, normal, sv.found);
             // reflectedColorInternal (src/world.zig:126-143)
             spawn_reflect = remaining != 0u && m.reflective != 0.0f;
             // refractedColorInternal (src/world.zig:149-186)
             if (remaining != 0u && m.transparency != 0.0f) {
                 const float n_ratio = n1 / n2;
-                const float cos_i = dot(eye, normal);
+                const float cos_i = dot<C>(eye, normal);
                 const float sin2_t = (n_ratio * n_ratio) * (1.0f - cos_i * cos_i);
                 if (!(sin2_t > 1.0f)) {
                     const float cos_t = sqrtf(1.0f - sin2_t);
@@ -934,7 +982,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RTX_WAVES_P
             }
             if (m.reflective > 0.0f && m.transparency > 0.0f) {
                 use_schlick = true;
-                reflectance = schlick(n1, n2, eye, normal);
+                reflectance = schlick<C>(n1, n2, eye, normal);
             }
         }
 
@@ -964,15 +1012,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RTX_WAVES_P
         }
         if (spawn_reflect) {
             const uint32_t slot = out_base + wa.ray_base + __popcll(m_refl & below);
-            p.q_org[qo][slot] = make_float4(over_point.x, over_point.y, over_point.z, over_point.w);
-            p.q_dir[qo][slot] = make_float4(reflectv.x, reflectv.y, reflectv.z, reflectv.w);
-            p.q_link[qo][slot] = make_uint2(node, __float_as_uint(reflective));
+            p.q_org[qo][slot] = make_float4(over_point.x, over_point.y, over_point.z, C ? __uint_as_float(node) : over_point.w);
+            p.q_dir[qo][slot] = make_float4(reflectv.x, reflectv.y, reflectv.z, C ? reflective : reflectv.w);
+            if (!C) p.q_link[qo][slot] = make_uint2(node, __float_as_uint(reflective));
         }
         if (spawn_refract) {
             const uint32_t slot = out_base + wa.ray_base + n_refl + __popcll(m_refr & below);
-            p.q_org[qo][slot] = make_float4(under_point.x, under_point.y, under_point.z, under_point.w);
-            p.q_dir[qo][slot] = make_float4(refract_dir.x, refract_dir.y, refract_dir.z, refract_dir.w);
-            p.q_link[qo][slot] = make_uint2(node | kLinkSlotBit, __float_as_uint(transparency));
+            p.q_org[qo][slot] =
+                make_float4(under_point.x, under_point.y, under_point.z, C ? __uint_as_float(node | kLinkSlotBit) : under_point.w);
+            p.q_dir[qo][slot] = make_float4(refract_dir.x, refract_dir.y, refract_dir.z, C ? transparency : refract_dir.w);
+            if (!C) p.q_link[qo][slot] = make_uint2(node | kLinkSlotBit, __float_as_uint(transparency));
         }
         DIAG_PHASE(7);  // node + child-ray stores
     }
@@ -1077,6 +1126,7 @@ struct rtx_scene {
     uint32_t n_shapes = 0, n_nodes = 0, n_materials = 0, n_patterns = 0;
     bool track_n1 = false;   // some material is transparent: n1/n2 matter
     bool can_spawn = false;  // some material is reflective or transparent: child rays exist
+    bool canon = false;      // the scene keeps w == 1 / w == 0 exact (see dot<C>)
     float light_position[4];
     float light_intensity[3];
 
@@ -1095,7 +1145,7 @@ struct rtx_scene {
     size_t canvas_floats = 0;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     int num_cus = 256;
-    int resident_blocks[2] = {0, 0};  // k_trace_shade blocks per CU: [0] queue-fed, [1] ray-generating
+    int resident_blocks[2][2] = {{0, 0}, {0, 0}};  // k_trace_shade blocks per CU: [canonical][0 queue-fed, 1 ray-generating]
     // profile = 1: pooled events bracketing each launch, pending until read back
     std::vector<hipEvent_t> prof_events;
     std::vector<int> prof_kind;  // per pair: 0 trace_shade, 1 combine
@@ -1184,29 +1234,29 @@ RowPlan plan_rows(const rtx_camera* cam, const rtx_opts* o) {
     return r;
 }
 
-template <bool GEN, bool TRACK>
-void launch_trace2(const Params& p, uint32_t level, uint32_t blocks, hipStream_t st) {
-    if (p.lds_bytes) hipLaunchKernelGGL((k_trace_shade<GEN, TRACK, true>), dim3(blocks), dim3(256), p.lds_bytes, st, p, level);
-    else hipLaunchKernelGGL((k_trace_shade<GEN, TRACK, false>), dim3(blocks), dim3(256), 0, st, p, level);
+// The k_trace_shade instantiation a frame uses, picked from run-time flags.
+using TraceKernel = void (*)(const Params, const uint32_t);
+template <bool GEN, bool TRACK, bool LDS>
+TraceKernel trace_kernel3(bool canon) {
+    return canon ? k_trace_shade<GEN, TRACK, LDS, true> : k_trace_shade<GEN, TRACK, LDS, false>;
+}
+template <bool GEN>
+TraceKernel trace_kernel(bool track, bool lds, bool canon) {
+    if (track) return lds ? trace_kernel3<GEN, true, true>(canon) : trace_kernel3<GEN, true, false>(canon);
+    return lds ? trace_kernel3<GEN, false, true>(canon) : trace_kernel3<GEN, false, false>(canon);
 }
 
 template <bool GEN>
 void launch_trace(const rtx_scene* s, const Params& p, uint32_t level, uint32_t blocks, hipStream_t st) {
-    if (s->track_n1) launch_trace2<GEN, true>(p, level, blocks, st);
-    else launch_trace2<GEN, false>(p, level, blocks, st);
+    hipLaunchKernelGGL(trace_kernel<GEN>(s->track_n1, p.lds_bytes != 0, p.canon != 0), dim3(blocks), dim3(256), p.lds_bytes, st, p, level);
 }
 
-// Resident 256-thread blocks per CU of the variant this scene launches (registers and LDS decide).
-template <bool GEN, bool TRACK>
-int resident_blocks2(uint32_t lds_bytes) {
-    int n = 0;
-    hipError_t e = lds_bytes ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_trace_shade<GEN, TRACK, true>, 256, lds_bytes)
-                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_trace_shade<GEN, TRACK, false>, 256, 0);
-    return (e == hipSuccess && n > 0) ? n : 4;
-}
+// Resident 256-thread blocks per CU of a variant (registers and LDS decide).
 template <bool GEN>
-int resident_blocks(const rtx_scene* s, uint32_t lds_bytes) {
-    return s->track_n1 ? resident_blocks2<GEN, true>(lds_bytes) : resident_blocks2<GEN, false>(lds_bytes);
+int resident_blocks(const rtx_scene* s, uint32_t lds_bytes, bool canon) {
+    int n = 0;
+    const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_kernel<GEN>(s->track_n1, lds_bytes != 0, canon), 256, lds_bytes);
+    return (e == hipSuccess && n > 0) ? n : 4;
 }
 
 int validate_desc(const rtx_scene_desc* d) {
@@ -1316,12 +1366,13 @@ int run_levels(rtx_scene* s, Params& p, uint32_t pixels, uint32_t level0_items, 
         const char* e = getenv("RTX_BLOCKS_PER_CU");
         return e ? atoi(e) : 0;
     }();
-    if (s->resident_blocks[0] == 0) {
-        s->resident_blocks[0] = resident_blocks<false>(s, p.lds_bytes);
-        s->resident_blocks[1] = resident_blocks<true>(s, p.lds_bytes);
+    const int cz = p.canon ? 1 : 0;
+    if (s->resident_blocks[cz][0] == 0) {
+        s->resident_blocks[cz][0] = resident_blocks<false>(s, p.lds_bytes, p.canon != 0);
+        s->resident_blocks[cz][1] = resident_blocks<true>(s, p.lds_bytes, p.canon != 0);
     }
     auto grid_for = [&](uint64_t items, bool gen) {
-        const uint32_t bpc = bpc_override > 0 ? (uint32_t)bpc_override : (uint32_t)s->resident_blocks[gen ? 1 : 0];
+        const uint32_t bpc = bpc_override > 0 ? (uint32_t)bpc_override : (uint32_t)s->resident_blocks[cz][gen ? 1 : 0];
         uint32_t max_blocks = ((uint32_t)s->num_cus * bpc) / kBlockQuantum * kBlockQuantum;
         if (max_blocks < kBlockQuantum) max_blocks = kBlockQuantum;
         uint64_t blocks = (items + 255) / 256;
@@ -1393,6 +1444,12 @@ int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_opts* opts, float
 
     Params p;
     fill_scene_params(s, p, depth);
+    {
+        const float* ci = cam->inverse_transform;
+        const bool cam_canon = ci[12] == 0.0f && ci[13] == 0.0f && ci[14] == 0.0f && ci[15] == 1.0f;
+        static const bool off = getenv("RTX_NO_CANON") != nullptr;  // A/B switch for experiments
+        p.canon = (s->canon && cam_canon && !off && !(opts && opts->full_w)) ? 1u : 0u;
+    }
     if (opts && opts->no_bvh) p.nodes = s->d_nodes_linear;
     std::memcpy(p.cam_inv, cam->inverse_transform, sizeof p.cam_inv);
     p.half_width = cam->half_width;
@@ -1541,6 +1598,14 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out) {
         sh.flags &= 0xFFu;  // bits above are the library's
         if (ident) sh.flags |= kShapeIdentity;
     }
+    // Canonical w lanes (see dot<C>): affine inverses, untranslated cubes, light at w == 1.
+    s->canon = desc->light_position[3] == 1.0f;
+    for (const rtx_shape& sh : shapes) {
+        const float* m = sh.inverse;
+        if (!(m[12] == 0.0f && m[13] == 0.0f && m[14] == 0.0f && m[15] == 1.0f)) s->canon = false;
+        if (sh.type == RTX_CUBE && !(m[3] == 0.0f && m[7] == 0.0f && m[11] == 0.0f)) s->canon = false;
+        if (sh.type == RTX_TRIANGLE && sh.normal[3] != 0.0f) s->canon = false;
+    }
     for (rtx_node& n : nodes) n.reserved[0] = n.reserved[1] = 0;
     std::vector<rtx_node> linear = nodes;
     std::vector<rtx_bvh::Node> bvh_nodes;
@@ -1652,14 +1717,31 @@ int rtx_color_at(rtx_scene* s, const float* origins, const float* directions, ui
     rc = ensure_canvas(s, (size_t)n * 3);
     if (rc) return rc;
     hipStream_t st = s->stream;
-    std::vector<uint2> links(n);
-    for (uint32_t i = 0; i < n; ++i) links[i] = make_uint2(i, 0x3F800000u /* weight 1.0f, unused at the root */);
-    HIP_TRY(hipMemcpyAsync(s->q_org[0], origins, (size_t)n * 16, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(s->q_dir[0], directions, (size_t)n * 16, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(s->q_link[0], links.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
+    // Canonical kernels need canonical rays too: origins with w == 1, directions with w == 0.
+    bool canon = s->canon;
+    for (uint32_t i = 0; i < n && canon; ++i) canon = origins[4 * i + 3] == 1.0f && directions[4 * i + 3] == 0.0f;
+    std::vector<float> org, dir;  // staging must outlive the copies (synchronised below)
+    std::vector<uint2> links;
+    if (canon) {  // level-0 records in the 32-byte format: link in origin.w, weight in direction.w
+        org.assign(origins, origins + (size_t)n * 4);
+        dir.assign(directions, directions + (size_t)n * 4);
+        for (uint32_t i = 0; i < n; ++i) {
+            std::memcpy(&org[4 * (size_t)i + 3], &i, sizeof i);
+            dir[4 * (size_t)i + 3] = 1.0f;  // weight, unused at the root
+        }
+        HIP_TRY(hipMemcpyAsync(s->q_org[0], org.data(), (size_t)n * 16, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(s->q_dir[0], dir.data(), (size_t)n * 16, hipMemcpyHostToDevice, st));
+    } else {
+        links.resize(n);
+        for (uint32_t i = 0; i < n; ++i) links[i] = make_uint2(i, 0x3F800000u /* weight 1.0f, unused at the root */);
+        HIP_TRY(hipMemcpyAsync(s->q_org[0], origins, (size_t)n * 16, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(s->q_dir[0], directions, (size_t)n * 16, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(s->q_link[0], links.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
+    }
     HIP_TRY(hipMemsetAsync(s->d_counters, 0, sizeof(Counters), st));
     Params p;
     fill_scene_params(s, p, depth);
+    p.canon = canon ? 1u : 0u;
     p.canvas = s->d_canvas;
     p.root_count = n;
     rc = run_levels<false>(s, p, n, n, st, false, true);

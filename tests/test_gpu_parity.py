@@ -47,6 +47,10 @@ def test_sample_matches_oracle(name):
     gpu, stats = scene.render(s.camera)
     compare(gpu, ref, name)
     assert (stats.rays_primary, stats.rays_shadow, stats.rays_secondary) == (counts.primary, counts.shadow, counts.secondary)
+    # the canonical-w kernels (chosen per scene) and the four-lane kernels give the same canvas
+    full, stats_full = scene.render(s.camera, full_w=True)
+    compare(full, ref, name + " (full_w)")
+    assert stats_full.rays_total == stats.rays_total
     scene.close()
 
 
@@ -67,6 +71,8 @@ def test_random_world_matches_oracle(seed):
     gpu, stats = scene.render(cam)
     compare(gpu, ref, "random world %d" % seed)
     assert stats.rays_total == counts.total
+    full, _ = scene.render(cam, full_w=True)
+    compare(full, ref, "random world %d (full_w)" % seed)
     scene.close()
 
 
@@ -82,6 +88,12 @@ def test_color_at_matches_oracle_including_rays_from_inside():
     gpu = scene.color_at(origins, dirs)
     ref = np.stack([o.color_at(s.world, origins[i], dirs[i]) for i in range(80)])
     compare(gpu[None], ref[None], "color_at")
+    # rays that are not canonical (origin w != 1, direction w != 0) take the four-lane kernels
+    origins[::7, 3] = 0.75
+    dirs[::5, 3] = 0.125
+    gpu = scene.color_at(origins, dirs)
+    ref = np.stack([o.color_at(s.world, origins[i], dirs[i]) for i in range(80)])
+    compare(gpu[None], ref[None], "color_at, general w")
     scene.close()
 
 
@@ -233,6 +245,8 @@ def test_teapot_matches_oracle_with_and_without_bvh():
     compare(gpu, ref, "teapot (BVH)")
     lin, stats_lin = scene.render(cam, no_bvh=True)
     compare(lin, ref, "teapot (linear)")
+    full, _ = scene.render(cam, full_w=True)
+    compare(full, ref, "teapot (BVH, full_w)")
     assert stats.rays_total == counts.total == stats_lin.rays_total
     scene.close()
 
@@ -364,3 +378,30 @@ def test_composite_at_7680x4320():
     ref, _ = o.render(cam, world, row_step=2160)  # the top row and the row through teapot and spheres
     ys = [0, 2160]
     compare(a[ys], ref[ys], "composite 7680x4320 sampled rows")
+
+
+def test_untranslated_cube_runs_canonical_and_translated_cube_does_not_change_it():
+    """A cube normal keeps its w lane through normalize (src/cube.zig:28-44): only an untranslated
+    cube leaves w == 0, so only then do the canonical-w kernels apply.  Both cases match the oracle."""
+    for shift in (0.0, 0.6):
+        mirror = st.default_attrs()
+        mirror.material.reflective = 0.6
+        mirror.material.transparency = 0.4
+        mirror.material.refractive_index = 1.3
+        cube = st.Cube(mirror)
+        cube.common_attrs.transform = su.compose(su.translation(shift, 0, 0), su.compose(su.rotation("y", 0.5), su.scaling(1.2, 0.7, 0.9)))
+        ball = st.Sphere(st.default_attrs())
+        ball.common_attrs.transform = su.translation(-2.0, 0.5, 1.0)
+        floor = st.Plane(st.default_attrs())
+        floor.common_attrs.transform = su.translation(0, -1.5, 0)
+        floor.common_attrs.material.reflective = 0.3
+        w, keep = st.make_world([-4, 6, -6, 1], [1, 1, 1], cubes=[cube], spheres=[ball], planes=[floor])
+        cam = su.default_camera(96, 64)
+        ref, counts = o.render(cam, w)
+        scene = rta.Scene(w)
+        gpu, stats = scene.render(cam)
+        compare(gpu, ref, "cube shift %g" % shift)
+        full, _ = scene.render(cam, full_w=True)
+        compare(full, ref, "cube shift %g (full_w)" % shift)
+        assert stats.rays_total == counts.total and stats.rays_secondary > 0
+        scene.close()
