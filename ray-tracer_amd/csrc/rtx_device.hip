@@ -145,7 +145,8 @@ struct Params {
     float4* node_b;  // reflected slot rgb, weight towards the parent
     float4* node_c;  // refracted slot rgb, link bits
     uint32_t node_off[kLevels];
-    uint32_t shard_cap0;  // level-0 items per shard; a shard holds shard_cap0 << d rays / nodes at level d
+    uint32_t shard_cap0;   // level-0 items per shard; a shard holds shard_cap0 << (d * level_shift) rays / nodes at level d
+    uint32_t level_shift;  // 1: some material spawns two children per hit (levels may double); 0: at most one
 
     Counters* counters;
     float* canvas;        // root results land here: 3 floats per root index
@@ -510,52 +511,61 @@ __device__ __forceinline__ void intersect_shape(V& v, const RT_CONST rtx_shape& 
 
 // Per-lane walk of one triangle BVH (threaded pre-order, no stack).  Only culling happens
 // here; every surviving triangle goes through the reference's test and the visitor.
+//
+// Two alternating phases ("while-while"): every lane first walks boxes until it holds a leaf
+// (or runs out of nodes), then the lanes test their leaf triangles together.  With a single
+// loop the lanes that sit on a leaf would run the long triangle test while all the others,
+// still walking boxes, idle through it — and the other way round.
 template <bool C, class V>
 __device__ __forceinline__ void traverse_bvh(V& v, const Params& p, uint32_t root, V4 o, V4 d) {
     const float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
     const rtx_bvh::Node* nodes = p.bvh_nodes;
     uint32_t n = root;
     const uint32_t end = nodes[root].skip;
-    while (n < end && !v.done()) {
-        const float4 a = *reinterpret_cast<const float4*>(&nodes[n].bmin[0]);
-        const float4 b = *reinterpret_cast<const float4*>(&nodes[n].bmax[0]);
-        const uint32_t skip = __float_as_uint(a.w), leaf = __float_as_uint(b.w);
-        // slab test; a NaN (0 * inf) drops out of fmin/fmax like in the reference's checkAxis
-        const float x0 = (a.x - o.x) * ix, x1 = (b.x - o.x) * ix;
-        const float y0 = (a.y - o.y) * iy, y1 = (b.y - o.y) * iy;
-        const float z0 = (a.z - o.z) * iz, z1 = (b.z - o.z) * iz;
-        const float tmin = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
-        const float tmax = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
-        const float slack = 1e-5f * (fabsf(tmin) + fabsf(tmax)) + 1e-6f;
-        const bool overlap = (tmin - slack <= tmax + slack) && (tmax + slack >= v.t_lo()) && (tmin - slack <= v.t_hi());
-        if (!overlap) {
-            n = skip;
-            continue;
-        }
-        if (leaf != rtx_bvh::kNoLeaf) {
-            const uint32_t first = leaf >> 3, count = leaf & 7u;
-            for (uint32_t k = 0; k < count; ++k) {
-                const rtx_bvh::Tri* tr = &p.bvh_tris[first + k];
-                const float4 q0 = *reinterpret_cast<const float4*>(&tr->p0[0]);
-                const float4 q1 = *reinterpret_cast<const float4*>(&tr->e0[0]);
-                const float4 q2 = *reinterpret_cast<const float4*>(&tr->e1[0]);
-                const uint32_t shape = __float_as_uint(q0.w), flags = __float_as_uint(q1.w);
-                V4 ro = o, rd = d;
-                if (!(flags & kShapeIdentity)) {
-                    const float* inv = p.shapes[shape].inverse;
-                    ro = mul_point<C>(inv, o);
-                    rd = mul_dir<C>(inv, d);
+    uint32_t tri = 0, tri_end = 0;  // pending leaf: triangles [tri, tri_end)
+    for (;;) {
+        while (tri == tri_end && n < end && !v.done()) {
+            const float4 a = *reinterpret_cast<const float4*>(&nodes[n].bmin[0]);
+            const float4 b = *reinterpret_cast<const float4*>(&nodes[n].bmax[0]);
+            const uint32_t skip = __float_as_uint(a.w), leaf = __float_as_uint(b.w);
+            // slab test; a NaN (0 * inf) drops out of fmin/fmax like in the reference's checkAxis
+            const float x0 = (a.x - o.x) * ix, x1 = (b.x - o.x) * ix;
+            const float y0 = (a.y - o.y) * iy, y1 = (b.y - o.y) * iy;
+            const float z0 = (a.z - o.z) * iz, z1 = (b.z - o.z) * iz;
+            const float tmin = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+            const float tmax = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+            const float slack = 1e-5f * (fabsf(tmin) + fabsf(tmax)) + 1e-6f;
+            const bool overlap = (tmin - slack <= tmax + slack) && (tmax + slack >= v.t_lo()) && (tmin - slack <= v.t_hi());
+            if (overlap && leaf == rtx_bvh::kNoLeaf) {
+                n = n + 1;  // first child
+            } else {
+                if (overlap) {
+                    tri = leaf >> 3;
+                    tri_end = tri + (leaf & 7u);
                 }
-                const float p0[3] = {q0.x, q0.y, q0.z}, e0[3] = {q1.x, q1.y, q1.z}, e1[3] = {q2.x, q2.y, q2.z};
-                float t;
-                if (triangle_root(ro, rd, p0, e0, e1, t)) {
-                    v.template hit<false>(t, shape);
-                    if (V::kTrack && !(flags & RTX_SHAPE_N1_INVISIBLE)) v.template pred<false>(t, shape);
-                }
+                n = skip;
             }
-            n = skip;
-        } else {
-            n = n + 1;
+        }
+        if (tri == tri_end) break;  // no leaf pending: this lane has run out of nodes (or is done)
+        while (tri < tri_end) {
+            const rtx_bvh::Tri* tr = &p.bvh_tris[tri];
+            const float4 q0 = *reinterpret_cast<const float4*>(&tr->p0[0]);
+            const float4 q1 = *reinterpret_cast<const float4*>(&tr->e0[0]);
+            const float4 q2 = *reinterpret_cast<const float4*>(&tr->e1[0]);
+            const uint32_t shape = __float_as_uint(q0.w), flags = __float_as_uint(q1.w);
+            V4 ro = o, rd = d;
+            if (!(flags & kShapeIdentity)) {
+                const float* inv = p.shapes[shape].inverse;
+                ro = mul_point<C>(inv, o);
+                rd = mul_dir<C>(inv, d);
+            }
+            const float p0[3] = {q0.x, q0.y, q0.z}, e0[3] = {q1.x, q1.y, q1.z}, e1[3] = {q2.x, q2.y, q2.z};
+            float t;
+            if (triangle_root(ro, rd, p0, e0, e1, t)) {
+                v.template hit<false>(t, shape);
+                if (V::kTrack && !(flags & RTX_SHAPE_N1_INVISIBLE)) v.template pred<false>(t, shape);
+            }
+            ++tri;
         }
     }
 }
@@ -860,10 +870,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RTX_WAVES_P
         count = static_cast<uint32_t>(sc->alloc[level - 1]);
         first = (wave / kShards) * 64u;
         stride = (n_waves / kShards) * 64u;
-        in_base = shard * (p.shard_cap0 << level);
+        in_base = shard * (p.shard_cap0 << (level * p.level_shift));
     }
-    const uint32_t out_base = shard * (p.shard_cap0 << (level + 1u));
-    const uint32_t node_base = p.node_off[level] + shard * (p.shard_cap0 << level);
+    const uint32_t out_base = shard * (p.shard_cap0 << ((level + 1u) * p.level_shift));
+    const uint32_t node_base = p.node_off[level] + shard * (p.shard_cap0 << (level * p.level_shift));
 
     uint32_t local_hits = 0, local_patterned = 0, local_transparent = 0;
     DIAG_DECL
@@ -1049,7 +1059,7 @@ __global__ __launch_bounds__(256) void k_combine(const Params p, const uint32_t 
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t shard = wave % kShards;
     const uint32_t count = static_cast<uint32_t>(p.counters->shard[shard].alloc[level] >> 32);
-    const uint32_t node_base = p.node_off[level] + shard * (p.shard_cap0 << level);
+    const uint32_t node_base = p.node_off[level] + shard * (p.shard_cap0 << (level * p.level_shift));
     for (uint32_t i = (wave / kShards) * 64u + lane; i < count; i += (n_waves / kShards) * 64u) {
         const uint32_t node = node_base + i;
         const float4 a = p.node_a[node], b = p.node_b[node], c = p.node_c[node];
@@ -1127,6 +1137,7 @@ struct rtx_scene {
     bool track_n1 = false;   // some material is transparent: n1/n2 matter
     bool can_spawn = false;  // some material is reflective or transparent: child rays exist
     bool canon = false;      // the scene keeps w == 1 / w == 0 exact (see dot<C>)
+    bool two_children = false;  // some material is reflective AND transparent: a hit may spawn two rays
     float light_position[4];
     float light_intensity[3];
 
@@ -1169,23 +1180,29 @@ void free_work(rtx_scene* s) {
     s->cap_pixels = 0;
 }
 
-// Worst-case sizing: a hit spawns at most two children, so level d holds at most
-// 2^d * pixels rays and as many interior nodes; no overflow path is needed.
-int ensure_work(rtx_scene* s, uint32_t pixels) {
-    if (pixels <= s->cap_pixels) return RTX_OK;
+// Worst-case sizing, so no overflow path is needed: a hit spawns a reflected child if its
+// material is reflective and a refracted one if it is transparent (src/world.zig:131,151).
+// If some material is both, level d holds at most 2^d * pixels rays and as many interior
+// nodes; otherwise a level never outgrows the pixels.  Queue 0 carries the even levels and
+// queue 1 the odd ones.  `need_link`: the general-w ray format keeps link/weight in a third array.
+int ensure_work(rtx_scene* s, uint32_t pixels, bool need_link) {
+    if (pixels <= s->cap_pixels && (!need_link || s->q_link[0])) return RTX_OK;
+    if (pixels < s->cap_pixels) pixels = s->cap_pixels;
+    need_link = need_link || s->q_link[0];
     free_work(s);
     // Level-0 chunks of 64 items are dealt round-robin to the shards, so a shard sees at most
-    // 64 * ceil(chunks / kShards) items at level 0 and 2^d times that at level d.
+    // 64 * ceil(chunks / kShards) items at level 0 and (1 << shift * d) times that at level d.
+    const uint32_t shift = s->two_children ? 1u : 0u;
     const uint32_t chunks = (pixels + 63u) / 64u;
     const uint32_t shard_cap0 = 64u * ((chunks + kShards - 1u) / kShards);
     const size_t per_level0 = (size_t)kShards * shard_cap0;
-    const size_t q_cap = per_level0 << kMaxDepth;  // largest level
+    const size_t q_cap[2] = {per_level0 << (shift * (kMaxDepth - 1)), per_level0 << (shift * kMaxDepth)};  // levels 4 and 5
     size_t node_cap = 0;
-    for (int l = 0; l < kMaxDepth; ++l) node_cap += per_level0 << l;
+    for (int l = 0; l < kMaxDepth; ++l) node_cap += per_level0 << (shift * l);
     for (int i = 0; i < 2; ++i) {
-        HIP_TRY(hipMalloc(&s->q_org[i], q_cap * sizeof(float4)));
-        HIP_TRY(hipMalloc(&s->q_dir[i], q_cap * sizeof(float4)));
-        HIP_TRY(hipMalloc(&s->q_link[i], q_cap * sizeof(uint2)));
+        HIP_TRY(hipMalloc(&s->q_org[i], q_cap[i] * sizeof(float4)));
+        HIP_TRY(hipMalloc(&s->q_dir[i], q_cap[i] * sizeof(float4)));
+        if (need_link) HIP_TRY(hipMalloc(&s->q_link[i], q_cap[i] * sizeof(uint2)));
     }
     HIP_TRY(hipMalloc(&s->node_a, node_cap * sizeof(float4)));
     HIP_TRY(hipMalloc(&s->node_b, node_cap * sizeof(float4)));
@@ -1353,10 +1370,11 @@ int collect_profile(rtx_scene* s, rtx_stats* out) {
 template <bool GEN>
 int run_levels(rtx_scene* s, Params& p, uint32_t pixels, uint32_t level0_items, hipStream_t st, bool prof, bool first) {
     p.shard_cap0 = s->shard_cap0;
+    p.level_shift = s->two_children ? 1u : 0u;
     uint32_t off = 0;
     for (int l = 0; l < kLevels; ++l) {
         p.node_off[l] = off;
-        if (l < kMaxDepth) off += (kShards * s->shard_cap0) << l;
+        if (l < kMaxDepth) off += (kShards * s->shard_cap0) << (l * p.level_shift);
     }
     // Every launch has a multiple of kShards waves (16 blocks of 4 waves), see k_trace_shade.
     constexpr uint32_t kBlockQuantum = kShards / 4u;
@@ -1396,14 +1414,14 @@ int run_levels(rtx_scene* s, Params& p, uint32_t pixels, uint32_t level0_items, 
     const uint32_t last_level = s->can_spawn ? p.depth : 0u;
     for (uint32_t level = 0; level <= last_level; ++level) {
         // Level 0 knows its size; deeper levels read theirs on the device and grid-stride.
-        const uint32_t blocks = grid_for(level == 0 ? level0_items : ((uint64_t)pixels << level), GEN && level == 0);
+        const uint32_t blocks = grid_for(level == 0 ? level0_items : ((uint64_t)pixels << (level * p.level_shift)), GEN && level == 0);
         mark(0);
         if (level == 0) launch_trace<GEN>(s, p, level, blocks, st);
         else launch_trace<false>(s, p, level, blocks, st);
         mark(-1);
     }
     for (int level = (int)last_level - 1; level >= 0; --level) {
-        const uint32_t blocks = grid_for((uint64_t)pixels << level, false);
+        const uint32_t blocks = grid_for((uint64_t)pixels << ((uint32_t)level * p.level_shift), false);
         mark(1);
         hipLaunchKernelGGL(k_combine, dim3(blocks), dim3(256), 0, st, p, (uint32_t)level);
         mark(-1);
@@ -1431,17 +1449,17 @@ int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_opts* opts, float
     const size_t out_rows = compact ? plan.rows_local : H;
 
     // Batch: whole 8-row bands, at most batch_pixels pixels.
-    uint32_t batch_pixels = (opts && opts->batch_pixels) ? opts->batch_pixels : (1u << 21);
-    if (batch_pixels > (1u << 22)) batch_pixels = 1u << 22;  // keeps (pixels << depth) inside 30 bits
+    // Default: a whole 3840x2160 frame per batch.  Deep levels of small batches hold too few rays
+    // to fill the chip (one wave iteration of a BVH scene takes tens of microseconds), and 288 GB
+    // of HBM pays for the worst-case queues (about 25 GB at this size when levels can double).
+    uint32_t batch_pixels = (opts && opts->batch_pixels) ? opts->batch_pixels : (1u << 23);
+    if (batch_pixels > (1u << 25)) batch_pixels = 1u << 25;  // keeps node indices (31 * pixels) inside 30 bits
     uint32_t rows_per_batch = (batch_pixels / W) & ~7u;
     if (rows_per_batch < 8) rows_per_batch = 8;
     if (rows_per_batch > ((plan.rows_local + 7u) & ~7u)) rows_per_batch = (plan.rows_local + 7u) & ~7u;
     if (rows_per_batch == 0) rows_per_batch = 8;
     const uint32_t tiles_x = (W + 7u) / 8u;
     const uint32_t cap = tiles_x * 8u * rows_per_batch;  // pixels incl. tile padding
-    rc = ensure_work(s, cap);
-    if (rc) return rc;
-
     Params p;
     fill_scene_params(s, p, depth);
     {
@@ -1450,6 +1468,16 @@ int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_opts* opts, float
         static const bool off = getenv("RTX_NO_CANON") != nullptr;  // A/B switch for experiments
         p.canon = (s->canon && cam_canon && !off && !(opts && opts->full_w)) ? 1u : 0u;
     }
+    rc = ensure_work(s, cap, p.canon == 0);
+    if (rc) return rc;
+    for (int i = 0; i < 2; ++i) {  // (re)allocated just now
+        p.q_org[i] = s->q_org[i];
+        p.q_dir[i] = s->q_dir[i];
+        p.q_link[i] = s->q_link[i];
+    }
+    p.node_a = s->node_a;
+    p.node_b = s->node_b;
+    p.node_c = s->node_c;
     if (opts && opts->no_bvh) p.nodes = s->d_nodes_linear;
     std::memcpy(p.cam_inv, cam->inverse_transform, sizeof p.cam_inv);
     p.half_width = cam->half_width;
@@ -1580,6 +1608,7 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out) {
         const rtx_material& m = desc->materials[desc->shapes[i].material];
         if (m.transparency != 0.0f) s->track_n1 = true;
         if (m.transparency != 0.0f || m.reflective != 0.0f) s->can_spawn = true;
+        if (m.transparency != 0.0f && m.reflective != 0.0f) s->two_children = true;
     }
 
     auto upload = [&](void** dst, const void* src, size_t bytes) -> hipError_t {
@@ -1712,14 +1741,14 @@ int rtx_color_at(rtx_scene* s, const float* origins, const float* directions, ui
     if (depth > kMaxDepth) return fail(RTX_E_INVALID, "depth %u exceeds ray_depth_limit %d", depth, kMaxDepth);
     if (n > (1u << 22)) return fail(RTX_E_INVALID, "at most %u rays per call", 1u << 22);
     HIP_TRY(hipSetDevice(s->device));
-    int rc = ensure_work(s, n);
+    // Canonical kernels need canonical rays too: origins with w == 1, directions with w == 0.
+    bool canon = s->canon;
+    for (uint32_t i = 0; i < n && canon; ++i) canon = origins[4 * i + 3] == 1.0f && directions[4 * i + 3] == 0.0f;
+    int rc = ensure_work(s, n, !canon);
     if (rc) return rc;
     rc = ensure_canvas(s, (size_t)n * 3);
     if (rc) return rc;
     hipStream_t st = s->stream;
-    // Canonical kernels need canonical rays too: origins with w == 1, directions with w == 0.
-    bool canon = s->canon;
-    for (uint32_t i = 0; i < n && canon; ++i) canon = origins[4 * i + 3] == 1.0f && directions[4 * i + 3] == 0.0f;
     std::vector<float> org, dir;  // staging must outlive the copies (synchronised below)
     std::vector<uint2> links;
     if (canon) {  // level-0 records in the 32-byte format: link in origin.w, weight in direction.w

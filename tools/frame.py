@@ -30,7 +30,7 @@ else:
 scene = rta.Scene(world)
 print("shapes", scene.n_shapes)
 for i in range(frames):
-    canvas, st = scene.render(cam, batch_pixels=batch, profile=True, no_bvh=no_bvh)
+    canvas, st = scene.render(cam, batch_pixels=batch, profile=os.environ.get("RTX_PROFILE", "1") != "0", no_bvh=no_bvh)
 if os.environ.get("RTX_SAVE"):
     import numpy as np
 
