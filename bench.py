@@ -41,6 +41,7 @@ tiling = importlib.import_module("ray-tracer_amd.tiling")
 WIDTH, HEIGHT = 1920, 1080
 SCENES = ["glass_spheres", "fresnel"]
 STRIP_ROWS = 16
+EVENT_EVERY = 4  # timed steps whose kernel launches are bracketed by HIP events (roofline.avg_launch_ms)
 VALU_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz, one flop per VALU op: FMA
                          # contraction is forbidden by parity, so mul and add issue separately
                          # (the FMA/packed peak is 157.3 TFLOP/s; DESIGN.md "Roofline")
@@ -102,6 +103,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-events", action="store_true", help="experiment: no per-launch HIP events in the timed loop")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -160,8 +162,10 @@ def main():
         frame(False)
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        frame(True)
+    for k in range(args.steps):
+        # Per-launch HIP events cost ~14 % of the step when every launch is bracketed (they break
+        # the back-to-back dispatch), so every EVENT_EVERY-th timed step carries them.
+        frame(not args.no_events and k % EVENT_EVERY == 0)
     fence()
     dt = time.perf_counter() - t0
 
@@ -180,7 +184,8 @@ def main():
         launches = sum(p.launches_trace_shade for p in prof)
         flops_step = sum(trace_shade_flops(s.world, st) for s, st in zip(samples, stats))
         avg_ms = ms_trace / max(launches, 1)
-        flops_per_launch = flops_step * args.steps / max(launches, 1)
+        profiled_steps = len(range(0, args.steps, EVENT_EVERY))
+        flops_per_launch = flops_step * profiled_steps / max(launches, 1)
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         out = {
             "metric": "Mrays/s (primary+shadow+secondary)",
@@ -204,9 +209,10 @@ def main():
                 "frac": achieved / VALU_PEAK_TFLOPS,
                 "traffic": None,
                 "flops_per_launch": flops_per_launch, "avg_launch_ms": avg_ms, "launches": launches,
-                "share_of_step": ms_trace / (dt * 1e3) if dt > 0 else None,
+                "share_of_step": (ms_trace / profiled_steps) / (dt / args.steps * 1e3) if dt > 0 and profiled_steps else None,
                 "note": "f32 VALU roofline (no MFMA: divergent per-lane scalar math); peak = non-FMA issue rate; "
-                        "rank 0's launches; HBM traffic per launch is in profiles/ (PMC pass)",
+                        "rank 0's launches of every %d-th timed step, bracketed by HIP events on the render stream; "
+                        "HBM traffic per launch is in profiles/ (PMC pass)" % EVENT_EVERY,
             },
         }
         if n == 1 and not args.no_cpu:

@@ -142,8 +142,9 @@ struct Params {
     float4* q_dir[2];
     uint2* q_link[2];
     float4* node_a;  // surface.rgb, reflectance
-    float4* node_b;  // reflected slot rgb, weight towards the parent
-    float4* node_c;  // refracted slot rgb, link bits
+    float4* node_b;  // reflected slot: rgb (w unused), written whole by the reflected child
+    float4* node_c;  // refracted slot: rgb (w unused), written whole by the refracted child
+    uint2* node_d;   // link bits towards the parent, weight towards the parent
     uint32_t node_off[kLevels];
     uint32_t shard_cap0;   // level-0 items per shard; a shard holds shard_cap0 << (d * level_shift) rays / nodes at level d
     uint32_t level_shift;  // 1: some material spawns two children per hit (levels may double); 0: at most one
@@ -528,7 +529,9 @@ __device__ __forceinline__ void traverse_bvh(V& v, const Params& p, uint32_t roo
             const float4 a = *reinterpret_cast<const float4*>(&nodes[n].bmin[0]);
             const float4 b = *reinterpret_cast<const float4*>(&nodes[n].bmax[0]);
             const uint32_t skip = __float_as_uint(a.w), leaf = __float_as_uint(b.w);
-            // slab test; a NaN (0 * inf) drops out of fmin/fmax like in the reference's checkAxis
+            // slab test; a NaN (0 * inf) drops out of fmin/fmax like in the reference's checkAxis.
+            // Kept as (bound - o) * (1 / d): the contracted form fma(bound, 1/d, -o/d) loses the
+            // small difference bound - o against a large o / d and would cull wrongly.
             const float x0 = (a.x - o.x) * ix, x1 = (b.x - o.x) * ix;
             const float y0 = (a.y - o.y) * iy, y1 = (b.y - o.y) * iy;
             const float z0 = (a.z - o.z) * iz, z1 = (b.z - o.z) * iz;
@@ -765,11 +768,9 @@ __device__ __forceinline__ void deliver(const Params& p, bool root, uint32_t lin
         px[2] = c.b;
     } else {
         const uint32_t parent = link & kLinkIndexMask;
+        // one 16-byte store per child: three scattered dword stores cost a 32-byte partial write each
         float4* slot = (link & kLinkSlotBit) ? &p.node_c[parent] : &p.node_b[parent];
-        float* f = reinterpret_cast<float*>(slot);
-        f[0] = c.r * weight;
-        f[1] = c.g * weight;
-        f[2] = c.b * weight;
+        *slot = make_float4(c.r * weight, c.g * weight, c.b * weight, 0.0f);
     }
 }
 
@@ -1016,9 +1017,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RTX_WAVES_P
         if (interior) {
             node = node_base + wa.node_base + __popcll(m_node & below);
             p.node_a[node] = make_float4(surface.r, surface.g, surface.b, reflectance);
-            p.node_b[node] = make_float4(0.0f, 0.0f, 0.0f, weight);
-            uint32_t bits = (link & (kLinkIndexMask | kLinkSlotBit)) | (use_schlick ? kLinkSchlickBit : 0u);
-            p.node_c[node] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(bits));
+            const uint32_t bits = (link & (kLinkIndexMask | kLinkSlotBit)) | (use_schlick ? kLinkSchlickBit : 0u);
+            p.node_d[node] = make_uint2(bits, __float_as_uint(weight));
+            // a slot without a child stays black (src/world.zig:131,151); the others are written by their child
+            if (!spawn_reflect) p.node_b[node] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (!spawn_refract) p.node_c[node] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
         if (spawn_reflect) {
             const uint32_t slot = out_base + wa.ray_base + __popcll(m_refl & below);
@@ -1063,10 +1066,11 @@ __global__ __launch_bounds__(256) void k_combine(const Params p, const uint32_t 
     for (uint32_t i = (wave / kShards) * 64u + lane; i < count; i += (n_waves / kShards) * 64u) {
         const uint32_t node = node_base + i;
         const float4 a = p.node_a[node], b = p.node_b[node], c = p.node_c[node];
-        const uint32_t bits = __float_as_uint(c.w);
+        const uint2 dd = p.node_d[node];
+        const uint32_t bits = dd.x;
         const Color out = combine(Color{a.x, a.y, a.z}, Color{b.x, b.y, b.z}, Color{c.x, c.y, c.z},
                                   (bits & kLinkSchlickBit) != 0u, a.w);
-        deliver(p, root, bits, b.w, out);
+        deliver(p, root, bits, __uint_as_float(dd.y), out);
     }
 }
 
@@ -1150,6 +1154,7 @@ struct rtx_scene {
     float4* node_a = nullptr;
     float4* node_b = nullptr;
     float4* node_c = nullptr;
+    uint2* node_d = nullptr;
     Counters* d_counters = nullptr;
     Totals* d_totals = nullptr;
     float* d_canvas = nullptr;  // staging canvas for the host-output entry points
@@ -1176,7 +1181,9 @@ void free_work(rtx_scene* s) {
     if (s->node_a) (void)hipFree(s->node_a);
     if (s->node_b) (void)hipFree(s->node_b);
     if (s->node_c) (void)hipFree(s->node_c);
+    if (s->node_d) (void)hipFree(s->node_d);
     s->node_a = s->node_b = s->node_c = nullptr;
+    s->node_d = nullptr;
     s->cap_pixels = 0;
 }
 
@@ -1207,6 +1214,7 @@ int ensure_work(rtx_scene* s, uint32_t pixels, bool need_link) {
     HIP_TRY(hipMalloc(&s->node_a, node_cap * sizeof(float4)));
     HIP_TRY(hipMalloc(&s->node_b, node_cap * sizeof(float4)));
     HIP_TRY(hipMalloc(&s->node_c, node_cap * sizeof(float4)));
+    HIP_TRY(hipMalloc(&s->node_d, node_cap * sizeof(uint2)));
     s->cap_pixels = pixels;
     s->shard_cap0 = shard_cap0;
     return RTX_OK;
@@ -1344,6 +1352,7 @@ void fill_scene_params(const rtx_scene* s, Params& p, uint32_t depth) {
     p.node_a = s->node_a;
     p.node_b = s->node_b;
     p.node_c = s->node_c;
+    p.node_d = s->node_d;
     p.counters = s->d_counters;
 }
 
@@ -1478,6 +1487,7 @@ int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_opts* opts, float
     p.node_a = s->node_a;
     p.node_b = s->node_b;
     p.node_c = s->node_c;
+    p.node_d = s->node_d;
     if (opts && opts->no_bvh) p.nodes = s->d_nodes_linear;
     std::memcpy(p.cam_inv, cam->inverse_transform, sizeof p.cam_inv);
     p.half_width = cam->half_width;
