@@ -16,7 +16,9 @@ over ranks between two barrier+synchronize pairs.
 
 Also reported in the same JSON line: `roofline` for the dominant kernel (k_trace_shade:
 algorithmic flops from SURVEY §8d's table x device event counts, over the HIP-event duration
-of its launches inside the timed region) and `cpu_baseline` (the oracle — a C port of the
+of its launches inside the timed region — every EVENT_EVERY-th timed step carries the events,
+since bracketing every launch slows the step by 14 % — plus the HBM bytes per launch of the
+newest committed PMC pass) and `cpu_baseline` (the oracle — a C port of the
 reference's algorithm, 8 static row bands like src/camera.zig:87-99 — timed on this box on
 a bounded row sample of the same workload; rank 0, N = 1 only).
 """
@@ -76,6 +78,20 @@ def trace_shade_flops(world, st):
     f += st.hits_patterned * F_PATTERN
     f += st.hits_transparent * F_REFRACT
     return f
+
+
+def measured_traffic():
+    """HBM bytes per k_trace_shade launch from the newest committed PMC pass (profiles/r*_traffic.json,
+    written by tools/profile_summarise.py from separate `rocprofv3 --pmc` runs of the same frames:
+    2 x FETCH_SIZE + WRITE_SIZE).  Counters cannot be read from inside this process, so the value is
+    the offline one; None if no pass has been committed."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        return float(json.load(f)["bytes_per_launch"]), os.path.relpath(files[-1], ROOT)
 
 
 def cpu_baseline(samples):
@@ -187,6 +203,7 @@ def main():
         profiled_steps = len(range(0, args.steps, EVENT_EVERY))
         flops_per_launch = flops_step * profiled_steps / max(launches, 1)
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        traffic, traffic_src = measured_traffic()
         out = {
             "metric": "Mrays/s (primary+shadow+secondary)",
             "value": rays_step * args.steps / dt / 1e6,
@@ -207,12 +224,13 @@ def main():
                 "bound": "valu", "kernel": "k_trace_shade",
                 "achieved": achieved, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / VALU_PEAK_TFLOPS,
-                "traffic": None,
+                "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
                 "flops_per_launch": flops_per_launch, "avg_launch_ms": avg_ms, "launches": launches,
                 "share_of_step": (ms_trace / profiled_steps) / (dt / args.steps * 1e3) if dt > 0 and profiled_steps else None,
                 "note": "f32 VALU roofline (no MFMA: divergent per-lane scalar math); peak = non-FMA issue rate; "
                         "rank 0's launches of every %d-th timed step, bracketed by HIP events on the render stream; "
-                        "HBM traffic per launch is in profiles/ (PMC pass)" % EVENT_EVERY,
+                        "traffic = HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE) from the committed PMC pass "
+                        "named in traffic_source" % EVENT_EVERY,
             },
         }
         if n == 1 and not args.no_cpu:
