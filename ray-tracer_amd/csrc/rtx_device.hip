@@ -123,6 +123,7 @@ struct Params {
     uint32_t lds_bytes;  // > 0: the scene tables are staged in this much dynamic LDS
     uint32_t track_n1;  // scene has a transparent material: track the n1 predecessor
     uint32_t canon;     // this frame runs the canonical-w kernels (ray records are 32 bytes)
+    uint32_t has_bvh;   // some gate node of `nodes` carries a triangle BVH
     uint32_t depth;
     float light_position[4];
     float light_intensity[3];
@@ -273,11 +274,34 @@ struct ClosestVisitor {
         }
     }
     static constexpr bool kTrack = TRACK;
+    // The BVH walk of the closest-hit pass looks ahead of the origin only: a predecessor among
+    // the mesh triangles is needed by few rays (those that end on a transparent material) and
+    // is collected for exactly those by a second walk (PredVisitor, traverse_pred).
+    static constexpr bool kBvhPred = false;
     __device__ __forceinline__ bool done() const { return false; }
-    // Range of t a BVH subtree must overlap to matter: with predecessor tracking the whole
-    // line counts (negative roots feed n1); otherwise only [0, current best].
-    __device__ __forceinline__ float t_lo() const { return TRACK ? -INFINITY : 0.0f; }
+    // Range of t a BVH subtree must overlap to matter: [0, current best].
+    __device__ __forceinline__ float t_lo() const { return 0.0f; }
     __device__ __forceinline__ float t_hi() const { return c.idx == kNone ? INFINITY : c.t; }
+};
+
+// The n1 predecessor among BVH triangles: the largest t < 0, ties to the highest insertion
+// index, merged into what the insertion-ordered walk found among the other shapes.
+struct PredVisitor {
+    float pred_t;
+    uint32_t pred_idx;
+    template <bool ORDERED>
+    __device__ __forceinline__ void hit(float, uint32_t) {}
+    template <bool ORDERED>
+    __device__ __forceinline__ void pred(float t, uint32_t s) {
+        if (t < 0.0f && (pred_idx == kNone || t > pred_t || (t == pred_t && s > pred_idx))) {
+            pred_t = t;
+            pred_idx = s;
+        }
+    }
+    static constexpr bool kBvhPred = true;
+    __device__ __forceinline__ bool done() const { return false; }
+    __device__ __forceinline__ float t_lo() const { return pred_idx == kNone ? -INFINITY : pred_t; }
+    __device__ __forceinline__ float t_hi() const { return 0.0f; }
 };
 
 // isShadowed (src/world.zig:97-120): the nearest t >= 0 is < distance  <=>  some root lies
@@ -292,6 +316,7 @@ struct ShadowVisitor {
     template <bool ORDERED>
     __device__ __forceinline__ void pred(float, uint32_t) {}
     static constexpr bool kTrack = false;
+    static constexpr bool kBvhPred = false;
     __device__ __forceinline__ bool done() const { return found; }
     __device__ __forceinline__ float t_lo() const { return 0.0f; }
     __device__ __forceinline__ float t_hi() const { return distance; }
@@ -566,7 +591,7 @@ __device__ __forceinline__ void traverse_bvh(V& v, const Params& p, uint32_t roo
             float t;
             if (triangle_root(ro, rd, p0, e0, e1, t)) {
                 v.template hit<false>(t, shape);
-                if (V::kTrack && !(flags & RTX_SHAPE_N1_INVISIBLE)) v.template pred<false>(t, shape);
+                if (V::kBvhPred && !(flags & RTX_SHAPE_N1_INVISIBLE)) v.template pred<false>(t, shape);
             }
             ++tri;
         }
@@ -578,7 +603,7 @@ __device__ __forceinline__ void traverse_bvh(V& v, const Params& p, uint32_t roo
 // through scalar loads); a lane whose ray failed a group's box is parked until the loop
 // leaves that group's subtree.  `lane_on` is false for padding lanes.  A node whose triangle
 // run has a BVH tests only its `n_linear` leading shapes linearly.
-template <bool C, class V>
+template <bool C, bool BVH, class V>
 __device__ __forceinline__ void traverse(V& v, const Params& p, V4 o, V4 d, bool lane_on) {
     uint32_t parked_until = lane_on ? 0u : kNone;  // node index at which this lane wakes up
     const RT_CONST rtx_node* nodes = as_const(p.nodes);
@@ -591,12 +616,29 @@ __device__ __forceinline__ void traverse(V& v, const Params& p, V4 o, V4 d, bool
             active = false;
         }
         if (__ballot(active) == 0ull) continue;
-        const uint32_t bvh_root = node.reserved[0];  // root + 1, 0 = no BVH
+        const uint32_t bvh_root = BVH ? node.reserved[0] : 0u;  // root + 1, 0 = no BVH
         const uint32_t first = node.first_shape;
         const uint32_t last = first + (bvh_root ? node.reserved[1] : node.n_shapes);
         for (uint32_t s = first; s < last; ++s) {
             if (active) intersect_shape<C>(v, shapes[s], s, o, d);
         }
+        if (BVH && bvh_root && active) traverse_bvh<C>(v, p, bvh_root - 1u, o, d);
+    }
+}
+
+// The gates again, for the BVH triangles only: the predecessor walk of the lanes in `lane_on`.
+template <bool C>
+__device__ __forceinline__ void traverse_pred(PredVisitor& v, const Params& p, V4 o, V4 d, bool lane_on) {
+    uint32_t parked_until = lane_on ? 0u : kNone;
+    const RT_CONST rtx_node* nodes = as_const(p.nodes);
+    for (uint32_t n = 0; n < p.n_nodes; ++n) {
+        const RT_CONST rtx_node& node = nodes[n];
+        bool active = n >= parked_until;
+        if (active && node.has_bounds && !bounds_hit(node, o, d)) {
+            parked_until = node.skip;
+            active = false;
+        }
+        const uint32_t bvh_root = node.reserved[0];
         if (bvh_root && active) traverse_bvh<C>(v, p, bvh_root - 1u, o, d);
     }
 }
@@ -824,15 +866,23 @@ struct LdsScene {
 // src/camera.zig:70-82) instead of the queue.  TRACK: keep the n1 predecessor.  LDS: the
 // scene tables fit in LDS (p.lds_bytes of dynamic shared memory).  C: canonical w lanes (see
 // dot<C>); rays then travel as two float4 (origin.xyz + link, direction.xyz + weight = 32 B)
-// instead of origin, direction and a link/weight pair (40 B).
-// Register budget: 5 waves per SIMD (<= 96 VGPRs).  Measured on configs[1] (with
-// -fno-slp-vectorize, see the Makefile): 4 waves 1.47 ms/step, 5 waves 1.39, 6 waves (spills)
-// 1.41, 8 waves (spills) 1.62.
+// instead of origin, direction and a link/weight pair (40 B).  BVH: some gate carries a triangle
+// BVH (scenes without one get kernels without the traversal code and its registers).
+// Register budget: 5 waves per SIMD (<= 96 VGPRs) for kernels that carry the BVH walk; measured
+// on configs[1] when every kernel carried it (with -fno-slp-vectorize, see the Makefile): 4 waves
+// 1.47 ms/step, 5 waves 1.39, 6 waves (spills) 1.41, 8 waves (spills) 1.62.  Kernels without
+// the BVH code need 75-80 VGPRs when they also leave the w lanes out (C) and get
+// RTX_WAVES_PER_EU_NOBVH; the four-lane ones would spill there and stay at 5.
 #ifndef RTX_WAVES_PER_EU
 #define RTX_WAVES_PER_EU 5
 #endif
-template <bool GEN, bool TRACK, bool LDS, bool C>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RTX_WAVES_PER_EU, RTX_WAVES_PER_EU))) void k_trace_shade(const Params p, const uint32_t level) {
+#ifndef RTX_WAVES_PER_EU_NOBVH
+#define RTX_WAVES_PER_EU_NOBVH 6
+#endif
+template <bool GEN, bool TRACK, bool LDS, bool C, bool BVH>
+__global__ __launch_bounds__(256)
+__attribute__((amdgpu_waves_per_eu((BVH || !C) ? RTX_WAVES_PER_EU : RTX_WAVES_PER_EU_NOBVH,
+                                   (BVH || !C) ? RTX_WAVES_PER_EU : RTX_WAVES_PER_EU_NOBVH))) void k_trace_shade(const Params p, const uint32_t level) {
     extern __shared__ uint4 lds_raw[];
     LdsScene tab{p.shapes, p.materials, p.patterns};
     if (LDS) {
@@ -929,8 +979,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RTX_WAVES_P
         // colorAtInternal: world.intersect + hit (src/world.zig:85-95)
         ClosestVisitor<TRACK> cv;
         cv.init();
-        traverse<C>(cv, p, o, d, on);
+        traverse<C, BVH>(cv, p, o, d, on);
         const bool is_hit = on && cv.c.idx != kNone;
+        if (TRACK && BVH) {
+            // n1 matters only where the hit material is transparent (src/world.zig:151,
+            // src/intersection.zig:165): only those lanes look for a predecessor among the meshes.
+            const bool need = is_hit && tab.materials[tab.shapes[cv.c.idx].material].transparency != 0.0f;
+            if (__ballot(need) != 0ull) {
+                PredVisitor pv{cv.c.pred_t, cv.c.pred_idx};
+                traverse_pred<C>(pv, p, o, d, need);
+                if (need) {
+                    cv.c.pred_t = pv.pred_t;
+                    cv.c.pred_idx = pv.pred_idx;
+                }
+            }
+        }
         DIAG_PHASE(1);  // closest-hit traversal
 
         // prepareComputations (src/intersection.zig:43-90) and the shadow ray
@@ -959,7 +1022,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RTX_WAVES_P
         ShadowVisitor sv;
         sv.distance = shadow_distance;
         sv.found = false;
-        traverse<C>(sv, p, over_point, shadow_dir, is_hit);
+        traverse<C, BVH>(sv, p, over_point, shadow_dir, is_hit);
         DIAG_PHASE(3);  // shadow traversal
 
         bool spawn_reflect = false, spawn_refract = false, use_schlick = false;
@@ -1161,7 +1224,7 @@ struct rtx_scene {
     size_t canvas_floats = 0;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     int num_cus = 256;
-    int resident_blocks[2][2] = {{0, 0}, {0, 0}};  // k_trace_shade blocks per CU: [canonical][0 queue-fed, 1 ray-generating]
+    int resident_blocks[4][2] = {};  // k_trace_shade blocks per CU: [canonical + 2 * bvh][0 queue-fed, 1 ray-generating]
     // profile = 1: pooled events bracketing each launch, pending until read back
     std::vector<hipEvent_t> prof_events;
     std::vector<int> prof_kind;  // per pair: 0 trace_shade, 1 combine
@@ -1262,25 +1325,26 @@ RowPlan plan_rows(const rtx_camera* cam, const rtx_opts* o) {
 // The k_trace_shade instantiation a frame uses, picked from run-time flags.
 using TraceKernel = void (*)(const Params, const uint32_t);
 template <bool GEN, bool TRACK, bool LDS>
-TraceKernel trace_kernel3(bool canon) {
-    return canon ? k_trace_shade<GEN, TRACK, LDS, true> : k_trace_shade<GEN, TRACK, LDS, false>;
+TraceKernel trace_kernel3(bool canon, bool bvh) {
+    if (bvh) return canon ? k_trace_shade<GEN, TRACK, LDS, true, true> : k_trace_shade<GEN, TRACK, LDS, false, true>;
+    return canon ? k_trace_shade<GEN, TRACK, LDS, true, false> : k_trace_shade<GEN, TRACK, LDS, false, false>;
 }
 template <bool GEN>
-TraceKernel trace_kernel(bool track, bool lds, bool canon) {
-    if (track) return lds ? trace_kernel3<GEN, true, true>(canon) : trace_kernel3<GEN, true, false>(canon);
-    return lds ? trace_kernel3<GEN, false, true>(canon) : trace_kernel3<GEN, false, false>(canon);
+TraceKernel trace_kernel(bool track, bool lds, bool canon, bool bvh) {
+    if (track) return lds ? trace_kernel3<GEN, true, true>(canon, bvh) : trace_kernel3<GEN, true, false>(canon, bvh);
+    return lds ? trace_kernel3<GEN, false, true>(canon, bvh) : trace_kernel3<GEN, false, false>(canon, bvh);
 }
 
 template <bool GEN>
 void launch_trace(const rtx_scene* s, const Params& p, uint32_t level, uint32_t blocks, hipStream_t st) {
-    hipLaunchKernelGGL(trace_kernel<GEN>(s->track_n1, p.lds_bytes != 0, p.canon != 0), dim3(blocks), dim3(256), p.lds_bytes, st, p, level);
+    hipLaunchKernelGGL(trace_kernel<GEN>(s->track_n1, p.lds_bytes != 0, p.canon != 0, p.has_bvh != 0), dim3(blocks), dim3(256), p.lds_bytes, st, p, level);
 }
 
 // Resident 256-thread blocks per CU of a variant (registers and LDS decide).
 template <bool GEN>
-int resident_blocks(const rtx_scene* s, uint32_t lds_bytes, bool canon) {
+int resident_blocks(const rtx_scene* s, uint32_t lds_bytes, bool canon, bool bvh) {
     int n = 0;
-    const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_kernel<GEN>(s->track_n1, lds_bytes != 0, canon), 256, lds_bytes);
+    const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_kernel<GEN>(s->track_n1, lds_bytes != 0, canon, bvh), 256, lds_bytes);
     return (e == hipSuccess && n > 0) ? n : 4;
 }
 
@@ -1328,6 +1392,7 @@ void fill_scene_params(const rtx_scene* s, Params& p, uint32_t depth) {
     p.nodes = s->d_nodes;
     p.bvh_nodes = s->d_bvh_nodes;
     p.bvh_tris = s->d_bvh_tris;
+    p.has_bvh = s->n_bvh_nodes ? 1u : 0u;
     p.materials = s->d_materials;
     p.patterns = s->d_patterns;
     p.n_nodes = s->n_nodes;
@@ -1393,10 +1458,10 @@ int run_levels(rtx_scene* s, Params& p, uint32_t pixels, uint32_t level0_items, 
         const char* e = getenv("RTX_BLOCKS_PER_CU");
         return e ? atoi(e) : 0;
     }();
-    const int cz = p.canon ? 1 : 0;
+    const int cz = (p.canon ? 1 : 0) + (p.has_bvh ? 2 : 0);
     if (s->resident_blocks[cz][0] == 0) {
-        s->resident_blocks[cz][0] = resident_blocks<false>(s, p.lds_bytes, p.canon != 0);
-        s->resident_blocks[cz][1] = resident_blocks<true>(s, p.lds_bytes, p.canon != 0);
+        s->resident_blocks[cz][0] = resident_blocks<false>(s, p.lds_bytes, p.canon != 0, p.has_bvh != 0);
+        s->resident_blocks[cz][1] = resident_blocks<true>(s, p.lds_bytes, p.canon != 0, p.has_bvh != 0);
     }
     auto grid_for = [&](uint64_t items, bool gen) {
         const uint32_t bpc = bpc_override > 0 ? (uint32_t)bpc_override : (uint32_t)s->resident_blocks[cz][gen ? 1 : 0];
@@ -1488,7 +1553,10 @@ int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_opts* opts, float
     p.node_b = s->node_b;
     p.node_c = s->node_c;
     p.node_d = s->node_d;
-    if (opts && opts->no_bvh) p.nodes = s->d_nodes_linear;
+    if (opts && opts->no_bvh) {
+        p.nodes = s->d_nodes_linear;
+        p.has_bvh = 0;
+    }
     std::memcpy(p.cam_inv, cam->inverse_transform, sizeof p.cam_inv);
     p.half_width = cam->half_width;
     p.half_height = cam->half_height;
