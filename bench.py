@@ -43,6 +43,7 @@ tiling = importlib.import_module("ray-tracer_amd.tiling")
 WIDTH, HEIGHT = 1920, 1080
 SCENES = ["glass_spheres", "fresnel"]
 STRIP_ROWS = 16
+REHEARSE = os.environ.get("RTX_BENCH_REHEARSE") == "1"  # not a measurement mode; see main()
 EVENT_EVERY = 4  # timed steps whose kernel launches are bracketed by HIP events (roofline.avg_launch_ms)
 VALU_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz, one flop per VALU op: FMA
                          # contraction is forbidden by parity, so mul and add issue separately
@@ -131,8 +132,12 @@ def main():
         import torch.distributed as dist
 
         assert world == n, "launch with torch.distributed.run --nproc-per-node %d" % n
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if REHEARSE:  # every rank on GPU 0, gloo between them: exercises this file's N > 1 logic on a 1-GPU box
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -152,17 +157,18 @@ def main():
     rgb = [torch.zeros((max_rows, WIDTH, 3), dtype=torch.float32, device=dev) for _ in scenes]
     rgb8 = [torch.zeros((max_rows, WIDTH, 3), dtype=torch.uint8, device=dev) for _ in scenes]
     gathered = full8 = None
+    gdev = torch.device("cpu") if REHEARSE else dev  # gloo gathers host tensors
     if n > 1 and rank == 0:
-        gathered = [[torch.zeros_like(rgb8[0]) for _ in range(n)] for _ in scenes]
-        full8 = [torch.zeros((HEIGHT, WIDTH, 3), dtype=torch.uint8, device=dev) for _ in scenes]
+        gathered = [[torch.zeros(rgb8[0].shape, dtype=torch.uint8, device=gdev) for _ in range(n)] for _ in scenes]
+        full8 = [torch.zeros((HEIGHT, WIDTH, 3), dtype=torch.uint8, device=gdev) for _ in scenes]
 
     def frame(profile):
         for i, sc in enumerate(scenes):
             sc.render_device(cams[i], rgb[i].data_ptr(), rgb8[i].data_ptr(), stream=stream, strips=strips,
                              compact_rows=n > 1, profile=profile)
             if n > 1:  # canvas gather: every peer sends its u8 strips straight to rank 0, which re-interleaves them
-                tiling.gather_canvas(rgb8[i], HEIGHT, STRIP_ROWS, out=full8[i] if rank == 0 else None,
-                                     slots=gathered[i] if rank == 0 else None)
+                tiling.gather_canvas(rgb8[i].cpu() if REHEARSE else rgb8[i], HEIGHT, STRIP_ROWS,
+                                     out=full8[i] if rank == 0 else None, slots=gathered[i] if rank == 0 else None)
 
     def fence():
         if n > 1:
@@ -186,7 +192,12 @@ def main():
     dt = time.perf_counter() - t0
 
     prof = [sc.profile_collect() for sc in scenes]
-    t = torch.tensor([dt, float(rays_local)], dtype=torch.float64, device=dev)
+    if REHEARSE and n > 1 and rank == 0:  # the gathered canvas must be the whole-frame render, byte for byte
+        for i, sc in enumerate(scenes):
+            whole, _ = sc.render(cams[i])
+            assert np.array_equal(full8[i].numpy(), rta.to_ppm_bytes(whole)), "gathered canvas differs for " + SCENES[i]
+        print("rehearsal: gathered canvases of %d ranks equal the whole-frame renders" % n, file=sys.stderr, flush=True)
+    t = torch.tensor([dt, float(rays_local)], dtype=torch.float64, device=gdev)
     if n > 1:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -203,7 +214,7 @@ def main():
         profiled_steps = len(range(0, args.steps, EVENT_EVERY))
         flops_per_launch = flops_step * profiled_steps / max(launches, 1)
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-        traffic, traffic_src = measured_traffic()
+        traffic, traffic_src = measured_traffic() if n == 1 else (None, None)  # the PMC pass is of whole frames
         out = {
             "metric": "Mrays/s (primary+shadow+secondary)",
             "value": rays_step * args.steps / dt / 1e6,

@@ -32,6 +32,19 @@ def slot_rows(height, strip_rows, world):
     return -(-strips // world) * strip_rows
 
 
+_ROW_INDEX = {}  # (height, strip_rows, world, rank, rows_quirk, device) -> long tensor of global rows
+
+
+def row_index(height, strip_rows, world, rank, rows_quirk, device):
+    """rows_of_rank as a device tensor, built once: the frame loop must not copy indices per frame."""
+    key = (height, strip_rows, world, rank, rows_quirk, str(device))
+    idx = _ROW_INDEX.get(key)
+    if idx is None:
+        idx = torch.as_tensor(rows_of_rank(height, strip_rows, world, rank, rows_quirk), dtype=torch.long, device=device)
+        _ROW_INDEX[key] = idx
+    return idx
+
+
 def gather_canvas(local, height, strip_rows, rows_quirk=True, group=None, out=None, slots=None):
     """Gather compact per-rank strips [slot_rows, W, C] on rank 0 into a full [H, W, C] canvas.
 
@@ -46,8 +59,7 @@ def gather_canvas(local, height, strip_rows, rows_quirk=True, group=None, out=No
     if out is None:
         out = torch.zeros((height,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     for r in range(world):
-        rows = rows_of_rank(height, strip_rows, world, r, rows_quirk)
-        if rows:
-            idx = torch.as_tensor(rows, dtype=torch.long, device=local.device)
-            out.index_copy_(0, idx, slots[r][: len(rows)])
+        idx = row_index(height, strip_rows, world, r, rows_quirk, local.device)
+        if idx.numel():
+            out.index_copy_(0, idx, slots[r][: idx.numel()])
     return out
