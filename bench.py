@@ -9,10 +9,16 @@ metric = Mrays/s, a ray being one colorAtInternal or one isShadowed call (SURVEY
 
     python bench.py --gpus N --steps K --warmup W
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): every rank holds the scenes,
-renders the 16-row strips s with s % N == rank of each frame, and the u8 strips are gathered
-on rank 0 over RCCL — the same frames split N ways, i.e. strong scaling.  Time is the max
-over ranks between two barrier+synchronize pairs.
+N > 1 (launched by torch.distributed.run, one rank per GPU; every rank holds the scenes):
+* default, "scaling": "weak" — a step is a batch of N frame pairs, rank r renders pair r whole
+  and every u8 canvas is gathered on rank 0 with one RCCL gather per step, overlapped with the
+  next step's rendering (two canvas buffers).  A configs[1] frame takes 0.5 ms on one GPU, below
+  the grain at which splitting it pays (launch floors bound the split at 4.9x on
+  8 GPUs), so frames, not strips, are the unit a node deals out at this size.
+* --split-frames, "scaling": "strong" — north_star's tile sharding: every frame is split into
+  16-row strips, rank r renders the strips s with s % N == r, the strips are gathered and
+  re-interleaved on rank 0 (the tool for 4K/8K frames; bound 6.7x at 8K).
+Time is the max over ranks between two barrier+synchronize pairs; all gathers are inside it.
 
 Also reported in the same JSON line: `roofline` for the dominant kernel (k_trace_shade:
 algorithmic flops from SURVEY §8d's table x device event counts, over the HIP-event duration
@@ -121,6 +127,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-events", action="store_true", help="experiment: no per-launch HIP events in the timed loop")
+    ap.add_argument("--split-frames", action="store_true",
+                    help="N > 1: split every frame into strips across the ranks (strong scaling) instead of dealing whole frames")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -151,52 +159,77 @@ def main():
     samples = [rta.Sample(name, WIDTH, HEIGHT) for name in SCENES]
     scenes = [rta.Scene(s.world, device=dev.index) for s in samples]
     cams = [rta.flatten_camera(s.camera) for s in samples]
-    strips = (STRIP_ROWS, n, rank) if n > 1 else None
+    split = n > 1 and args.split_frames
+    strips = (STRIP_ROWS, n, rank) if split else None
     rows = [rta.rows_for(c, strips=strips) for c in cams]
-    max_rows = tiling.slot_rows(HEIGHT, STRIP_ROWS, n) if n > 1 else HEIGHT  # equal-size gather slots
+    max_rows = tiling.slot_rows(HEIGHT, STRIP_ROWS, n) if split else HEIGHT  # equal-size gather slots
     rgb = [torch.zeros((max_rows, WIDTH, 3), dtype=torch.float32, device=dev) for _ in scenes]
-    rgb8 = [torch.zeros((max_rows, WIDTH, 3), dtype=torch.uint8, device=dev) for _ in scenes]
-    gathered = full8 = None
+    # Two u8 canvas sets: while set b travels to rank 0 the next step renders into set 1 - b.
+    rgb8 = [torch.zeros((len(scenes), max_rows, WIDTH, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
     gdev = torch.device("cpu") if REHEARSE else dev  # gloo gathers host tensors
+    slots = full8 = None
     if n > 1 and rank == 0:
-        gathered = [[torch.zeros(rgb8[0].shape, dtype=torch.uint8, device=gdev) for _ in range(n)] for _ in scenes]
-        full8 = [torch.zeros((HEIGHT, WIDTH, 3), dtype=torch.uint8, device=gdev) for _ in scenes]
+        slots = [[torch.zeros(rgb8[0].shape, dtype=torch.uint8, device=gdev) for _ in range(n)] for _ in range(2)]
+        if split:
+            full8 = torch.zeros((len(scenes), HEIGHT, WIDTH, 3), dtype=torch.uint8, device=gdev)
+    pending = {}  # canvas set -> the gather in flight on it
 
-    def frame(profile):
+    def finish(b):
+        """Wait for the gather of canvas set b; rank 0 of a split run puts the strips back in place."""
+        work, _src = pending.pop(b, (None, None))  # _src: keeps the rehearsal's host copy alive
+        if work is None:
+            return
+        work.wait()  # RCCL: the render stream waits, the host does not
+        if split and rank == 0:
+            for r in range(n):
+                idx = tiling.row_index(HEIGHT, STRIP_ROWS, n, r, True, gdev)
+                if idx.numel():
+                    full8.index_copy_(1, idx, slots[b][r][:, : idx.numel()])
+
+    def frame(k, profile):
+        b = k & 1
+        finish(b)  # set b is free again once its last gather has landed
         for i, sc in enumerate(scenes):
-            sc.render_device(cams[i], rgb[i].data_ptr(), rgb8[i].data_ptr(), stream=stream, strips=strips,
-                             compact_rows=n > 1, profile=profile)
-            if n > 1:  # canvas gather: every peer sends its u8 strips straight to rank 0, which re-interleaves them
-                tiling.gather_canvas(rgb8[i].cpu() if REHEARSE else rgb8[i], HEIGHT, STRIP_ROWS,
-                                     out=full8[i] if rank == 0 else None, slots=gathered[i] if rank == 0 else None)
+            sc.render_device(cams[i], rgb[i].data_ptr(), rgb8[b][i].data_ptr(), stream=stream, strips=strips,
+                             compact_rows=split, profile=profile)
+        if n > 1:  # canvas exchange: every peer sends its u8 canvases (or strips) straight to rank 0
+            src = rgb8[b].cpu() if REHEARSE else rgb8[b]
+            pending[b] = (dist.gather(src, slots[b] if rank == 0 else None, dst=0, async_op=True), src)
 
     def fence():
+        for b in list(pending):
+            finish(b)
         if n > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
     # Ray counts of this rank's share (deterministic per frame): one counted pass, untimed.
-    stats = [sc.render_device(cams[i], rgb[i].data_ptr(), None, stream=stream, strips=strips, compact_rows=n > 1,
+    stats = [sc.render_device(cams[i], rgb[i].data_ptr(), None, stream=stream, strips=strips, compact_rows=split,
                               want_stats=True) for i, sc in enumerate(scenes)]
     rays_local = sum(s.rays_total for s in stats)
 
-    for _ in range(args.warmup):
-        frame(False)
+    for k in range(args.warmup):
+        frame(k, False)
     fence()
     t0 = time.perf_counter()
     for k in range(args.steps):
         # Per-launch HIP events cost ~14 % of the step when every launch is bracketed (they break
         # the back-to-back dispatch), so every EVENT_EVERY-th timed step carries them.
-        frame(not args.no_events and k % EVENT_EVERY == 0)
+        frame(k, not args.no_events and k % EVENT_EVERY == 0)
     fence()
     dt = time.perf_counter() - t0
 
     prof = [sc.profile_collect() for sc in scenes]
-    if REHEARSE and n > 1 and rank == 0:  # the gathered canvas must be the whole-frame render, byte for byte
-        for i, sc in enumerate(scenes):
-            whole, _ = sc.render(cams[i])
-            assert np.array_equal(full8[i].numpy(), rta.to_ppm_bytes(whole)), "gathered canvas differs for " + SCENES[i]
-        print("rehearsal: gathered canvases of %d ranks equal the whole-frame renders" % n, file=sys.stderr, flush=True)
+    if REHEARSE and n > 1 and rank == 0:  # what arrived must be the whole-frame renders, byte for byte
+        whole = np.stack([rta.to_ppm_bytes(sc.render(cams[i])[0]) for i, sc in enumerate(scenes)])
+        for b in range(2):
+            if split:
+                assert np.array_equal(full8.numpy(), whole), "re-interleaved strips differ from the whole-frame render"
+            else:
+                for r in range(n):
+                    assert np.array_equal(slots[b][r].numpy(), whole), "canvas set %d of rank %d differs" % (b, r)
+        print("rehearsal (%s): the canvases gathered from %d ranks equal the whole-frame renders" % (
+            "split frames" if split else "whole frames", n), file=sys.stderr, flush=True)
     t = torch.tensor([dt, float(rays_local)], dtype=torch.float64, device=gdev)
     if n > 1:
         tmax = t.clone()
@@ -222,14 +255,19 @@ def main():
             "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": "strong" if split else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "glass_spheres + fresnel (samples/*.zig scenes) at 1920x1080, depth 5, one step = both frames",
-                "rays_per_step": int(rays_step), "frame_ms": dt / args.steps * 1e3 / len(SCENES),
-                "parallelism": "1 GPU" if n == 1 else "%d ranks x 16-row strips, RCCL gather of the u8 canvas" % n,
+                "workload": "glass_spheres + fresnel (samples/*.zig scenes) at 1920x1080, depth 5, one step = "
+                            + ("both frames" if n == 1 or split else "%d frame pairs (one per rank)" % n),
+                "rays_per_step": int(rays_step),
+                "frame_ms": dt / args.steps * 1e3 / (len(SCENES) * (1 if n == 1 or split else n)),
+                "parallelism": "1 GPU" if n == 1 else (
+                    "%d ranks x 16-row strips of every frame, RCCL gather + re-interleave of the u8 strips on rank 0" % n if split
+                    else "%d ranks x whole frames, one RCCL gather of the u8 canvases per step on rank 0, overlapped "
+                         "with the next step" % n),
             },
             "roofline": {
                 "bound": "valu", "kernel": "k_trace_shade",
