@@ -1163,6 +1163,10 @@ EXPORT void oracle_set_over_eps_factor(float f) { over_eps_factor = f; }
  * them (tests/test_oracle_golden.py), which pins everything else on the path. */
 static int legacy_light_at_point = 0;
 EXPORT void oracle_set_legacy_light_at_point(int on) { legacy_light_at_point = on; }
+/* ray_depth_limit (world.zig:20) is a constant 5 in the reference; the product exposes it as
+ * rtx_opts.depth (1..5), so the checker can be told to cut the recursion at the same level. */
+static int depth_limit_opt = RAY_DEPTH_LIMIT;
+EXPORT void oracle_set_depth_limit(int depth) { depth_limit_opt = (depth >= 1 && depth <= RAY_DEPTH_LIMIT) ? depth : RAY_DEPTH_LIMIT; }
 
 static color reflected_color_internal(ctx* c, const computation* comps, unsigned remaining) { /* world.zig:126-143 */
     color black = {{0, 0, 0}};
@@ -1333,7 +1337,7 @@ EXPORT int oracle_render(const rt_camera* cam, const rt_world* world, float* can
         tc[i].final_row = tc[i].start_row + rows_per_thread;
         if (!rows_quirk && i == number_of_threads - 1) tc[i].final_row = h;
         tc[i].row_step = row_step;
-        tc[i].depth_limit = RAY_DEPTH_LIMIT;
+        tc[i].depth_limit = depth_limit_opt;
         if (pthread_create(&threads[i], NULL, render_internal, &tc[i]) != 0) return -1;
     }
     rt_ray_counts total = {0, 0, 0};
@@ -1352,9 +1356,9 @@ EXPORT void oracle_color_at(const rt_world* world, const rt_ray* r, float rgb[3]
     ctx c;
     memset(&c, 0, sizeof c);
     c.world = world;
-    c.depth_limit = RAY_DEPTH_LIMIT;
+    c.depth_limit = depth_limit_opt;
     ray rr = {tup_from(r->origin), tup_from(r->direction)};
-    color col = color_at_internal(&c, rr, RAY_DEPTH_LIMIT);
+    color col = color_at_internal(&c, rr, (unsigned)depth_limit_opt);
     rgb[0] = col.c[0];
     rgb[1] = col.c[1];
     rgb[2] = col.c[2];

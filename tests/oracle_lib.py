@@ -36,6 +36,7 @@ def lib():
     P = C.POINTER
     L.oracle_set_libm.argtypes = [C.c_int]
     L.oracle_set_containers.argtypes = [C.c_int]
+    L.oracle_set_depth_limit.argtypes = [C.c_int]
     L.oracle_sample.restype = C.c_void_p
     L.oracle_sample.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32]
     L.oracle_scene_world.restype = P(st.World)

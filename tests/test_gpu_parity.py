@@ -405,3 +405,70 @@ def test_untranslated_cube_runs_canonical_and_translated_cube_does_not_change_it
         compare(full, ref, "cube shift %g (full_w)" % shift)
         assert stats.rays_total == counts.total and stats.rays_secondary > 0
         scene.close()
+
+
+# ---- edge cases: empty and ragged inputs, many shapes, nested gates ---------------------------
+
+def test_empty_world_and_ragged_canvas_sizes():
+    w, keep = st.make_world([0, 10, -10, 1], [1, 1, 1])
+    for width, height in [(1, 8), (7, 9), (13, 24), (65, 16)]:
+        cam = su.default_camera(width, height)
+        scene = rta.Scene(w)
+        gpu, stats = scene.render(cam)
+        assert gpu.shape == (height, width, 3) and not gpu.any()
+        assert stats.rays_primary == width * 8 * (height // 8) and stats.rays_shadow == 0 and stats.rays_secondary == 0
+        scene.close()
+    # a real scene on the same ragged sizes (tiles are 8x8: edges are padded lanes)
+    s = rta.Sample("sphere_world", 37, 19)
+    ref, counts = o.render(s.camera, s.world)
+    scene = rta.Scene(s.world)
+    gpu, stats = scene.render(s.camera)
+    compare(gpu, ref, "37x19")
+    gpu_all, stats_all = scene.render(s.camera, rows_quirk=False)
+    ref_all, _ = o.render(s.camera, s.world, rows_quirk=False)
+    compare(gpu_all, ref_all, "37x19, all rows")
+    assert stats.rays_total == counts.total and stats_all.rays_primary == 37 * 19
+    assert rta.Scene(w).color_at(np.zeros((0, 4), np.float32), np.zeros((0, 4), np.float32)).shape == (0, 3)
+    scene.close()
+
+
+def test_many_shapes_take_the_global_memory_tables():
+    # 300 small spheres: the scene tables no longer fit the 32 KB LDS budget
+    rng = np.random.default_rng(11)
+    spheres = []
+    for k in range(300):
+        a = st.default_attrs()
+        a.material.color[:] = rng.uniform(0.1, 1.0, 3).astype(np.float32)
+        a.material.reflective = 0.3 if k % 7 == 0 else 0.0
+        a.material.transparency = 0.5 if k % 11 == 0 else 0.0
+        a.material.refractive_index = 1.3
+        sp = st.Sphere(a)
+        x, y, z = rng.uniform(-4, 4), rng.uniform(-2, 2), rng.uniform(0, 6)
+        sp.common_attrs.transform = su.compose(su.translation(float(x), float(y), float(z)), su.scaling(0.25, 0.25, 0.25))
+        spheres.append(sp)
+    w, keep = st.make_world([-5, 8, -8, 1], [1, 1, 1], spheres=spheres)
+    cam = su.default_camera(80, 48)
+    ref, counts = o.render(cam, w)
+    scene = rta.Scene(w)
+    gpu, stats = scene.render(cam)
+    compare(gpu, ref, "300 spheres")
+    assert stats.rays_total == counts.total and stats.rays_secondary > 0
+    scene.close()
+
+
+@pytest.mark.parametrize("depth", [1, 2, 3, 4, 5])
+def test_every_depth_limit_matches_the_oracle(depth):
+    s = rta.Sample("glass_spheres", 64, 64)
+    o.lib().oracle_set_depth_limit(depth)
+    try:
+        ref, counts = o.render(s.camera, s.world)
+    finally:
+        o.lib().oracle_set_depth_limit(5)
+    scene = rta.Scene(s.world)
+    gpu, stats = scene.render(s.camera, depth=depth)
+    compare(gpu, ref, "depth %d" % depth)
+    assert stats.rays_total == counts.total
+    full, stats5 = scene.render(s.camera)
+    assert sum(stats.level_rays[depth + 1:]) == 0
+    assert list(stats.level_rays[: depth + 1]) == list(stats5.level_rays[: depth + 1])  # the same tree, cut
+    scene.close()
