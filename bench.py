@@ -50,7 +50,7 @@ WIDTH, HEIGHT = 1920, 1080
 SCENES = ["glass_spheres", "fresnel"]
 STRIP_ROWS = 16
 REHEARSE = os.environ.get("RTX_BENCH_REHEARSE") == "1"  # not a measurement mode; see main()
-EVENT_EVERY = 4  # timed steps whose kernel launches are bracketed by HIP events (roofline.avg_launch_ms)
+EVENT_EVERY = 10  # timed steps whose kernel launches are bracketed by HIP events (roofline.avg_launch_ms)
 VALU_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz, one flop per VALU op: FMA
                          # contraction is forbidden by parity, so mul and add issue separately
                          # (the FMA/packed peak is 157.3 TFLOP/s; DESIGN.md "Roofline")
@@ -155,6 +155,11 @@ def main():
     tstream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(tstream)
     stream = tstream.cuda_stream
+    # The two frames of a step are independent: the second scene renders on a stream of its own,
+    # so its kernels fill the tails (and the empty deep levels) of the first one's (+7 %).  Steps
+    # that carry per-launch events stay on one stream: their durations are those of each kernel
+    # running alone.  RTX_BENCH_ONE_STREAM=1 switches the overlap off.
+    side = None if os.environ.get("RTX_BENCH_ONE_STREAM") == "1" else torch.cuda.Stream(device=dev)
 
     samples = [rta.Sample(name, WIDTH, HEIGHT) for name in SCENES]
     scenes = [rta.Scene(s.world, device=dev.index) for s in samples]
@@ -189,9 +194,14 @@ def main():
     def frame(k, profile):
         b = k & 1
         finish(b)  # set b is free again once its last gather has landed
+        if side is not None:
+            side.wait_stream(tstream)
         for i, sc in enumerate(scenes):
-            sc.render_device(cams[i], rgb[i].data_ptr(), rgb8[b][i].data_ptr(), stream=stream, strips=strips,
+            st_i = side.cuda_stream if (side is not None and i == 1 and not profile) else stream
+            sc.render_device(cams[i], rgb[i].data_ptr(), rgb8[b][i].data_ptr(), stream=st_i, strips=strips,
                              compact_rows=split, profile=profile)
+        if side is not None:
+            tstream.wait_stream(side)
         if n > 1:  # canvas exchange: every peer sends its u8 canvases (or strips) straight to rank 0
             src = rgb8[b].cpu() if REHEARSE else rgb8[b]
             pending[b] = (dist.gather(src, slots[b] if rank == 0 else None, dst=0, async_op=True), src)
@@ -214,7 +224,8 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         # Per-launch HIP events cost ~14 % of the step when every launch is bracketed (they break
-        # the back-to-back dispatch), so every EVENT_EVERY-th timed step carries them.
+        # the back-to-back dispatch), so every EVENT_EVERY-th timed step carries them (and runs
+        # its two frames one after the other, see `side`).
         frame(k, not args.no_events and k % EVENT_EVERY == 0)
     fence()
     dt = time.perf_counter() - t0
@@ -277,7 +288,8 @@ def main():
                 "flops_per_launch": flops_per_launch, "avg_launch_ms": avg_ms, "launches": launches,
                 "share_of_step": (ms_trace / profiled_steps) / (dt / args.steps * 1e3) if dt > 0 and profiled_steps else None,
                 "note": "f32 VALU roofline (no MFMA: divergent per-lane scalar math); peak = non-FMA issue rate; "
-                        "rank 0's launches of every %d-th timed step, bracketed by HIP events on the render stream; "
+                        "rank 0's launches of every %d-th timed step, bracketed by HIP events on the render stream "
+                        "(those steps render their two frames back to back, the others overlap them on two streams); "
                         "traffic = HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE) from the committed PMC pass "
                         "named in traffic_source" % EVENT_EVERY,
             },
