@@ -146,6 +146,11 @@ typedef struct rtx_opts {
     uint32_t no_bvh;       /* 1: test every triangle of a group linearly (A/B check of the triangle BVH) */
     uint32_t full_w;       /* 1: keep the w lane of every tuple operation even where the scene makes it an exact
                               0 / 1 (A/B check of the canonical-w kernels; same canvas, slower) */
+    uint32_t lanes;        /* batches of a frame alternate between this many work-buffer sets on as many
+                              streams, so one batch's kernels fill the tails of the other's: 1 or 2;
+                              0 = auto (2 for multi-level frames of >= 4 Mpx, where it cuts the frame time
+                              by 13-17 %; 1 otherwise: the fork/join costs more than it wins on short frames) */
+    uint32_t reserved;
 } rtx_opts;
 
 typedef struct rtx_stats {

@@ -1189,6 +1189,25 @@ __global__ void k_quantise(const float* rgb, uint8_t* out, size_t n) {
 
 // ---------------------------------------------------------------------- host side
 
+constexpr int kLanes = 2;
+
+// One set of work buffers, sized for `cap_pixels` pixels per batch at depth kMaxDepth.
+struct WorkSet {
+    uint32_t cap_pixels = 0;
+    uint32_t shard_cap0 = 0;  // level-0 items per shard the buffers were sized for
+    float4* q_org[2] = {nullptr, nullptr};
+    float4* q_dir[2] = {nullptr, nullptr};
+    uint2* q_link[2] = {nullptr, nullptr};
+    float4* node_a = nullptr;
+    float4* node_b = nullptr;
+    float4* node_c = nullptr;
+    uint2* node_d = nullptr;
+    Counters* d_counters = nullptr;
+    Totals* d_totals = nullptr;
+    hipStream_t stream = nullptr;  // lane stream (lane 0 of a single-lane frame runs on the caller's)
+    hipEvent_t done = nullptr;
+};
+
 struct rtx_scene {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -1208,18 +1227,11 @@ struct rtx_scene {
     float light_position[4];
     float light_intensity[3];
 
-    // work buffers, sized for `cap_pixels` pixels per batch at depth kMaxDepth
-    uint32_t cap_pixels = 0;
-    uint32_t shard_cap0 = 0;  // level-0 items per shard the buffers were sized for
-    float4* q_org[2] = {nullptr, nullptr};
-    float4* q_dir[2] = {nullptr, nullptr};
-    uint2* q_link[2] = {nullptr, nullptr};
-    float4* node_a = nullptr;
-    float4* node_b = nullptr;
-    float4* node_c = nullptr;
-    uint2* node_d = nullptr;
-    Counters* d_counters = nullptr;
-    Totals* d_totals = nullptr;
+    // Work buffers come in kLanes independent sets: the batches of one frame alternate between
+    // them on two streams, so the kernels of one batch fill the tails (and the empty deep
+    // levels) of the other's.
+    WorkSet ws[kLanes];
+    hipEvent_t ev_fork = nullptr;
     float* d_canvas = nullptr;  // staging canvas for the host-output entry points
     size_t canvas_floats = 0;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
@@ -1233,21 +1245,21 @@ struct rtx_scene {
 
 namespace {
 
-void free_work(rtx_scene* s) {
+void free_work(WorkSet* w) {
     for (int i = 0; i < 2; ++i) {
-        if (s->q_org[i]) (void)hipFree(s->q_org[i]);
-        if (s->q_dir[i]) (void)hipFree(s->q_dir[i]);
-        if (s->q_link[i]) (void)hipFree(s->q_link[i]);
-        s->q_org[i] = s->q_dir[i] = nullptr;
-        s->q_link[i] = nullptr;
+        if (w->q_org[i]) (void)hipFree(w->q_org[i]);
+        if (w->q_dir[i]) (void)hipFree(w->q_dir[i]);
+        if (w->q_link[i]) (void)hipFree(w->q_link[i]);
+        w->q_org[i] = w->q_dir[i] = nullptr;
+        w->q_link[i] = nullptr;
     }
-    if (s->node_a) (void)hipFree(s->node_a);
-    if (s->node_b) (void)hipFree(s->node_b);
-    if (s->node_c) (void)hipFree(s->node_c);
-    if (s->node_d) (void)hipFree(s->node_d);
-    s->node_a = s->node_b = s->node_c = nullptr;
-    s->node_d = nullptr;
-    s->cap_pixels = 0;
+    if (w->node_a) (void)hipFree(w->node_a);
+    if (w->node_b) (void)hipFree(w->node_b);
+    if (w->node_c) (void)hipFree(w->node_c);
+    if (w->node_d) (void)hipFree(w->node_d);
+    w->node_a = w->node_b = w->node_c = nullptr;
+    w->node_d = nullptr;
+    w->cap_pixels = 0;
 }
 
 // Worst-case sizing, so no overflow path is needed: a hit spawns a reflected child if its
@@ -1255,11 +1267,11 @@ void free_work(rtx_scene* s) {
 // If some material is both, level d holds at most 2^d * pixels rays and as many interior
 // nodes; otherwise a level never outgrows the pixels.  Queue 0 carries the even levels and
 // queue 1 the odd ones.  `need_link`: the general-w ray format keeps link/weight in a third array.
-int ensure_work(rtx_scene* s, uint32_t pixels, bool need_link) {
-    if (pixels <= s->cap_pixels && (!need_link || s->q_link[0])) return RTX_OK;
-    if (pixels < s->cap_pixels) pixels = s->cap_pixels;
-    need_link = need_link || s->q_link[0];
-    free_work(s);
+int ensure_work(const rtx_scene* s, WorkSet* w, uint32_t pixels, bool need_link) {
+    if (pixels <= w->cap_pixels && (!need_link || w->q_link[0])) return RTX_OK;
+    if (pixels < w->cap_pixels) pixels = w->cap_pixels;
+    need_link = need_link || w->q_link[0];
+    free_work(w);
     // Level-0 chunks of 64 items are dealt round-robin to the shards, so a shard sees at most
     // 64 * ceil(chunks / kShards) items at level 0 and (1 << shift * d) times that at level d.
     const uint32_t shift = s->two_children ? 1u : 0u;
@@ -1270,17 +1282,31 @@ int ensure_work(rtx_scene* s, uint32_t pixels, bool need_link) {
     size_t node_cap = 0;
     for (int l = 0; l < kMaxDepth; ++l) node_cap += per_level0 << (shift * l);
     for (int i = 0; i < 2; ++i) {
-        HIP_TRY(hipMalloc(&s->q_org[i], q_cap[i] * sizeof(float4)));
-        HIP_TRY(hipMalloc(&s->q_dir[i], q_cap[i] * sizeof(float4)));
-        if (need_link) HIP_TRY(hipMalloc(&s->q_link[i], q_cap[i] * sizeof(uint2)));
+        HIP_TRY(hipMalloc(&w->q_org[i], q_cap[i] * sizeof(float4)));
+        HIP_TRY(hipMalloc(&w->q_dir[i], q_cap[i] * sizeof(float4)));
+        if (need_link) HIP_TRY(hipMalloc(&w->q_link[i], q_cap[i] * sizeof(uint2)));
     }
-    HIP_TRY(hipMalloc(&s->node_a, node_cap * sizeof(float4)));
-    HIP_TRY(hipMalloc(&s->node_b, node_cap * sizeof(float4)));
-    HIP_TRY(hipMalloc(&s->node_c, node_cap * sizeof(float4)));
-    HIP_TRY(hipMalloc(&s->node_d, node_cap * sizeof(uint2)));
-    s->cap_pixels = pixels;
-    s->shard_cap0 = shard_cap0;
+    HIP_TRY(hipMalloc(&w->node_a, node_cap * sizeof(float4)));
+    HIP_TRY(hipMalloc(&w->node_b, node_cap * sizeof(float4)));
+    HIP_TRY(hipMalloc(&w->node_c, node_cap * sizeof(float4)));
+    HIP_TRY(hipMalloc(&w->node_d, node_cap * sizeof(uint2)));
+    w->cap_pixels = pixels;
+    w->shard_cap0 = shard_cap0;
     return RTX_OK;
+}
+
+// Point a batch's parameters at a work set.
+void bind_work(Params& p, const WorkSet& w) {
+    for (int i = 0; i < 2; ++i) {
+        p.q_org[i] = w.q_org[i];
+        p.q_dir[i] = w.q_dir[i];
+        p.q_link[i] = w.q_link[i];
+    }
+    p.node_a = w.node_a;
+    p.node_b = w.node_b;
+    p.node_c = w.node_c;
+    p.node_d = w.node_d;
+    p.counters = w.d_counters;
 }
 
 int ensure_canvas(rtx_scene* s, size_t floats) {
@@ -1409,16 +1435,6 @@ void fill_scene_params(const rtx_scene* s, Params& p, uint32_t depth) {
     std::memcpy(p.light_position, s->light_position, sizeof p.light_position);
     std::memcpy(p.light_intensity, s->light_intensity, sizeof p.light_intensity);
     p.over_eps = kEpsilon * 100.0f;  // f32 product, one ulp below 0.001f (src/world.zig:55)
-    for (int i = 0; i < 2; ++i) {
-        p.q_org[i] = s->q_org[i];
-        p.q_dir[i] = s->q_dir[i];
-        p.q_link[i] = s->q_link[i];
-    }
-    p.node_a = s->node_a;
-    p.node_b = s->node_b;
-    p.node_c = s->node_c;
-    p.node_d = s->node_d;
-    p.counters = s->d_counters;
 }
 
 // Sum the pending profile events into `out` and mark them consumed (stream must be idle).
@@ -1442,13 +1458,15 @@ int collect_profile(rtx_scene* s, rtx_stats* out) {
 // Run the levels for one batch whose level-0 rays are either generated (GEN) or already in
 // queue 0 (rtx_color_at).
 template <bool GEN>
-int run_levels(rtx_scene* s, Params& p, uint32_t pixels, uint32_t level0_items, hipStream_t st, bool prof, bool first) {
-    p.shard_cap0 = s->shard_cap0;
+int run_levels(rtx_scene* s, const WorkSet& w, Params& p, uint32_t pixels, uint32_t level0_items, hipStream_t st, bool prof,
+               bool first) {
+    bind_work(p, w);
+    p.shard_cap0 = w.shard_cap0;
     p.level_shift = s->two_children ? 1u : 0u;
     uint32_t off = 0;
     for (int l = 0; l < kLevels; ++l) {
         p.node_off[l] = off;
-        if (l < kMaxDepth) off += (kShards * s->shard_cap0) << (l * p.level_shift);
+        if (l < kMaxDepth) off += (kShards * w.shard_cap0) << (l * p.level_shift);
     }
     // Every launch has a multiple of kShards waves (16 blocks of 4 waves), see k_trace_shade.
     constexpr uint32_t kBlockQuantum = kShards / 4u;
@@ -1500,7 +1518,7 @@ int run_levels(rtx_scene* s, Params& p, uint32_t pixels, uint32_t level0_items, 
         hipLaunchKernelGGL(k_combine, dim3(blocks), dim3(256), 0, st, p, (uint32_t)level);
         mark(-1);
     }
-    hipLaunchKernelGGL(k_accumulate, dim3(1), dim3(kShards), 0, st, s->d_counters, s->d_totals, level0_items ? pixels : 0u, last_level,
+    hipLaunchKernelGGL(k_accumulate, dim3(1), dim3(kShards), 0, st, w.d_counters, w.d_totals, level0_items ? pixels : 0u, last_level,
                        first ? 1u : 0u);
     HIP_TRY(hipGetLastError());
     return RTX_OK;
@@ -1532,6 +1550,24 @@ int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_opts* opts, float
     if (rows_per_batch < 8) rows_per_batch = 8;
     if (rows_per_batch > ((plan.rows_local + 7u) & ~7u)) rows_per_batch = (plan.rows_local + 7u) & ~7u;
     if (rows_per_batch == 0) rows_per_batch = 8;
+    // Two lanes: a frame that would be one batch is cut in two halves that run on two streams
+    // with their own work buffers, so each half's kernels fill the other's tails and empty
+    // levels.  Frames with per-launch events (profile) stay on one lane: their kernels must run
+    // alone to be timed.  rtx_opts.lanes picks; 0 = auto: only multi-level frames of >= 4 Mpx,
+    // because the fork/join between streams costs tens of microseconds per frame (a 1080p frame
+    // loop loses 14 % to it, a 4K mesh frame gains 13 %).  RTX_LANES overrides auto (A/B).
+    static const int lanes_env = [] {
+        const char* e = getenv("RTX_LANES");
+        return e ? atoi(e) : 0;
+    }();
+    int lanes = (int)((opts && opts->lanes) ? opts->lanes : (lanes_env > 0 ? (uint32_t)lanes_env : 0u));
+    if (lanes > kLanes) return fail(RTX_E_INVALID, "lanes %d exceeds %d", lanes, kLanes);
+    if (lanes == 0) lanes = (s->can_spawn && (uint64_t)plan.rows_local * W >= (1u << 22)) ? kLanes : 1;
+    if (profile || plan.rows_local < 64u) lanes = 1;
+    if (lanes > 1) {
+        const uint32_t half = ((plan.rows_local + (uint32_t)lanes - 1u) / (uint32_t)lanes + 7u) & ~7u;
+        if (half < rows_per_batch) rows_per_batch = half;
+    }
     const uint32_t tiles_x = (W + 7u) / 8u;
     const uint32_t cap = tiles_x * 8u * rows_per_batch;  // pixels incl. tile padding
     Params p;
@@ -1542,17 +1578,10 @@ int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_opts* opts, float
         static const bool off = getenv("RTX_NO_CANON") != nullptr;  // A/B switch for experiments
         p.canon = (s->canon && cam_canon && !off && !(opts && opts->full_w)) ? 1u : 0u;
     }
-    rc = ensure_work(s, cap, p.canon == 0);
-    if (rc) return rc;
-    for (int i = 0; i < 2; ++i) {  // (re)allocated just now
-        p.q_org[i] = s->q_org[i];
-        p.q_dir[i] = s->q_dir[i];
-        p.q_link[i] = s->q_link[i];
+    for (int l = 0; l < lanes; ++l) {
+        rc = ensure_work(s, &s->ws[l], cap, p.canon == 0);
+        if (rc) return rc;
     }
-    p.node_a = s->node_a;
-    p.node_b = s->node_b;
-    p.node_c = s->node_c;
-    p.node_d = s->node_d;
     if (opts && opts->no_bvh) {
         p.nodes = s->d_nodes_linear;
         p.has_bvh = 0;
@@ -1573,17 +1602,34 @@ int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_opts* opts, float
     // Canvas starts black (canvas.zig:23-25); rows never rendered stay black.  Every rendered
     // pixel is written exactly once, so only a canvas with unrendered rows needs the fill.
     if (!compact && plan.rows_local < H) HIP_TRY(hipMemsetAsync(d_rgb, 0, out_rows * W * 3 * sizeof(float), st));
+    // Lane streams start after everything queued on the caller's stream so far (one lane: the
+    // caller's stream itself carries the work).
+    hipStream_t lane_stream[kLanes];
+    for (int l = 0; l < lanes; ++l) lane_stream[l] = lanes == 1 ? st : s->ws[l].stream;
+    if (lanes > 1) {
+        HIP_TRY(hipEventRecord(s->ev_fork, st));
+        for (int l = 0; l < lanes; ++l) HIP_TRY(hipStreamWaitEvent(lane_stream[l], s->ev_fork, 0));
+    }
     // The shard counters are left at zero by k_accumulate; clear them anyway in case an earlier
     // call on this scene stopped half way.
-    HIP_TRY(hipMemsetAsync(s->d_counters, 0, sizeof(Counters), st));
+    for (int l = 0; l < lanes; ++l) HIP_TRY(hipMemsetAsync(s->ws[l].d_counters, 0, sizeof(Counters), lane_stream[l]));
 
-    for (uint32_t row0 = 0; row0 < plan.rows_local; row0 += rows_per_batch) {
+    uint32_t batch = 0;
+    for (uint32_t row0 = 0; row0 < plan.rows_local; row0 += rows_per_batch, ++batch) {
         const uint32_t n_rows = (plan.rows_local - row0 < rows_per_batch) ? plan.rows_local - row0 : rows_per_batch;
         p.row0 = row0;
         p.n_rows = n_rows;
         const uint32_t items = tiles_x * ((n_rows + 7u) / 8u) * 64u;
-        rc = run_levels<true>(s, p, cap, items, st, profile, row0 == 0);
+        const int l = (int)(batch % (uint32_t)lanes);
+        rc = run_levels<true>(s, s->ws[l], p, cap, items, lane_stream[l], profile, batch < (uint32_t)lanes);
         if (rc) return rc;
+    }
+    const int lanes_used = batch < (uint32_t)lanes ? (int)batch : lanes;
+    if (lanes > 1) {
+        for (int l = 0; l < lanes; ++l) {
+            HIP_TRY(hipEventRecord(s->ws[l].done, lane_stream[l]));
+            HIP_TRY(hipStreamWaitEvent(st, s->ws[l].done, 0));
+        }
     }
     if (d_rgb8) {
         const size_t n = out_rows * W * 3;
@@ -1594,9 +1640,18 @@ int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_opts* opts, float
 
     if (stats) {
         std::memset(stats, 0, sizeof *stats);
-        Totals t;
-        HIP_TRY(hipMemcpyAsync(&t, s->d_totals, sizeof t, hipMemcpyDeviceToHost, st));
+        Totals t{}, part[kLanes];
+        for (int l = 0; l < lanes_used; ++l) HIP_TRY(hipMemcpyAsync(&part[l], s->ws[l].d_totals, sizeof(Totals), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
+        for (int l = 0; l < lanes_used; ++l) {
+            for (int k = 0; k < kLevels; ++k) {
+                t.level_rays[k] += part[l].level_rays[k];
+                t.level_hits[k] += part[l].level_hits[k];
+            }
+            t.nodes += part[l].nodes;
+            t.hits_patterned += part[l].hits_patterned;
+            t.hits_transparent += part[l].hits_transparent;
+        }
         // k_accumulate counts tile padding at level 0; the rays that exist are the pixels.
         stats->rays_primary = (uint64_t)plan.rows_local * W;
         stats->level_rays[0] = stats->rays_primary;
@@ -1737,8 +1792,13 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out) {
     HIP_TRY_S(upload((void**)&s->d_bvh_tris, bvh_tris.data(), sizeof(rtx_bvh::Tri) * bvh_tris.size()));
     HIP_TRY_S(upload((void**)&s->d_materials, desc->materials, sizeof(rtx_material) * desc->n_materials));
     HIP_TRY_S(upload((void**)&s->d_patterns, desc->patterns, sizeof(rtx_pattern) * desc->n_patterns));
-    HIP_TRY_S(hipMalloc(&s->d_counters, sizeof(Counters)));
-    HIP_TRY_S(hipMalloc(&s->d_totals, sizeof(Totals)));
+    HIP_TRY_S(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
+    for (WorkSet& w : s->ws) {
+        HIP_TRY_S(hipMalloc(&w.d_counters, sizeof(Counters)));
+        HIP_TRY_S(hipMalloc(&w.d_totals, sizeof(Totals)));
+        HIP_TRY_S(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
+        HIP_TRY_S(hipEventCreateWithFlags(&w.done, hipEventDisableTiming));
+    }
 #undef HIP_TRY_S
     *out = s;
     return RTX_OK;
@@ -1748,7 +1808,15 @@ void rtx_scene_destroy(rtx_scene* s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
-    free_work(s);
+    for (WorkSet& w : s->ws) {
+        if (w.stream) (void)hipStreamSynchronize(w.stream);
+        free_work(&w);
+        if (w.d_counters) (void)hipFree(w.d_counters);
+        if (w.d_totals) (void)hipFree(w.d_totals);
+        if (w.done) (void)hipEventDestroy(w.done);
+        if (w.stream) (void)hipStreamDestroy(w.stream);
+    }
+    if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
     if (s->d_canvas) (void)hipFree(s->d_canvas);
     if (s->d_shapes) (void)hipFree(s->d_shapes);
     if (s->d_nodes) (void)hipFree(s->d_nodes);
@@ -1757,8 +1825,6 @@ void rtx_scene_destroy(rtx_scene* s) {
     if (s->d_bvh_tris) (void)hipFree(s->d_bvh_tris);
     if (s->d_materials) (void)hipFree(s->d_materials);
     if (s->d_patterns) (void)hipFree(s->d_patterns);
-    if (s->d_counters) (void)hipFree(s->d_counters);
-    if (s->d_totals) (void)hipFree(s->d_totals);
     for (hipEvent_t e : s->prof_events) (void)hipEventDestroy(e);
     if (s->ev_begin) (void)hipEventDestroy(s->ev_begin);
     if (s->ev_end) (void)hipEventDestroy(s->ev_end);
@@ -1822,7 +1888,8 @@ int rtx_color_at(rtx_scene* s, const float* origins, const float* directions, ui
     // Canonical kernels need canonical rays too: origins with w == 1, directions with w == 0.
     bool canon = s->canon;
     for (uint32_t i = 0; i < n && canon; ++i) canon = origins[4 * i + 3] == 1.0f && directions[4 * i + 3] == 0.0f;
-    int rc = ensure_work(s, n, !canon);
+    WorkSet& w = s->ws[0];
+    int rc = ensure_work(s, &w, n, !canon);
     if (rc) return rc;
     rc = ensure_canvas(s, (size_t)n * 3);
     if (rc) return rc;
@@ -1836,22 +1903,22 @@ int rtx_color_at(rtx_scene* s, const float* origins, const float* directions, ui
             std::memcpy(&org[4 * (size_t)i + 3], &i, sizeof i);
             dir[4 * (size_t)i + 3] = 1.0f;  // weight, unused at the root
         }
-        HIP_TRY(hipMemcpyAsync(s->q_org[0], org.data(), (size_t)n * 16, hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemcpyAsync(s->q_dir[0], dir.data(), (size_t)n * 16, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(w.q_org[0], org.data(), (size_t)n * 16, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(w.q_dir[0], dir.data(), (size_t)n * 16, hipMemcpyHostToDevice, st));
     } else {
         links.resize(n);
         for (uint32_t i = 0; i < n; ++i) links[i] = make_uint2(i, 0x3F800000u /* weight 1.0f, unused at the root */);
-        HIP_TRY(hipMemcpyAsync(s->q_org[0], origins, (size_t)n * 16, hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemcpyAsync(s->q_dir[0], directions, (size_t)n * 16, hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemcpyAsync(s->q_link[0], links.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(w.q_org[0], origins, (size_t)n * 16, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(w.q_dir[0], directions, (size_t)n * 16, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(w.q_link[0], links.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
     }
-    HIP_TRY(hipMemsetAsync(s->d_counters, 0, sizeof(Counters), st));
+    HIP_TRY(hipMemsetAsync(w.d_counters, 0, sizeof(Counters), st));
     Params p;
     fill_scene_params(s, p, depth);
     p.canon = canon ? 1u : 0u;
     p.canvas = s->d_canvas;
     p.root_count = n;
-    rc = run_levels<false>(s, p, n, n, st, false, true);
+    rc = run_levels<false>(s, w, p, n, n, st, false, true);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(rgb_out, s->d_canvas, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));

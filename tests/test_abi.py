@@ -43,7 +43,7 @@ def test_struct_sizes_match_the_headers():
     assert C.sizeof(rta.RtxPattern) == 96
     assert C.sizeof(rta.RtxNode) == 48
     assert C.sizeof(rta.RtxCamera) == 20 + 64
-    assert C.sizeof(rta.RtxOpts) == 40
+    assert C.sizeof(rta.RtxOpts) == 48
 
 
 def test_defaults_match_reference_material():

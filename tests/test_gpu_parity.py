@@ -472,3 +472,22 @@ def test_every_depth_limit_matches_the_oracle(depth):
     assert sum(stats.level_rays[depth + 1:]) == 0
     assert list(stats.level_rays[: depth + 1]) == list(stats5.level_rays[: depth + 1])  # the same tree, cut
     scene.close()
+
+
+def test_two_lanes_equal_one_lane():
+    # rtx_opts.lanes: batches alternate between two work-buffer sets on two streams
+    s = rta.Sample("glass_spheres", 640, 360)
+    scene = rta.Scene(s.world)
+    one, s1 = scene.render(s.camera, lanes=1)
+    two, s2 = scene.render(s.camera, lanes=2)
+    many, s3 = scene.render(s.camera, lanes=2, batch_pixels=640 * 40)  # nine batches over two lanes
+    assert one.tobytes() == two.tobytes() == many.tobytes()
+    for a in (s2, s3):
+        assert (a.rays_primary, a.rays_shadow, a.rays_secondary, a.nodes) == (s1.rays_primary, s1.rays_shadow, s1.rays_secondary, s1.nodes)
+        assert list(a.level_rays) == list(s1.level_rays) and list(a.level_hits) == list(s1.level_hits)
+    part, _ = scene.render(s.camera, lanes=2, strips=(16, 3, 1), compact_rows=True)
+    ys = [y for y in range(360) if (y // 16) % 3 == 1]
+    assert part.tobytes() == one[ys].tobytes()
+    with pytest.raises(rta.RtxError):
+        scene.render(s.camera, lanes=3)
+    scene.close()
