@@ -212,6 +212,17 @@ int rtx_profile_collect(rtx_scene* scene, rtx_stats* out);
 int rtx_color_at(rtx_scene* scene, const float* origins, const float* directions, uint32_t n, uint32_t depth,
                  float* rgb_out);
 
+/*
+ * Host-only self-check of the triangle BVHs rtx_scene_create would build for `desc` (new design,
+ * no counterpart in the reference, whose groups are brute force: src/group.zig:55-87).  Validates
+ * every tree (forward skips, each hittable triangle in exactly one leaf) and, for n rays (n*4 f32
+ * each), compares the closest hit and the n1 predecessor the traversal code finds — the same
+ * source the kernels compile — with brute force over the same triangles.  Needs no device.
+ * Returns 0 and the counts, or RTX_E_INVALID with a message when a tree is malformed.
+ */
+int rtx_bvh_selftest(const rtx_scene_desc* desc, const float* origins, const float* directions, uint32_t n,
+                     uint32_t* n_bvh_nodes, uint32_t* n_bvh_tris, uint32_t* mismatches);
+
 const char* rtx_last_error(void);
 
 #pragma GCC visibility pop

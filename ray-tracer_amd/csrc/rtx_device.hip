@@ -71,6 +71,12 @@ struct V4 {
     float x, y, z, w;
 };
 
+// The traversal code of the triangle BVH (and the tuple math under it) also compiles for the
+// host: rtx_bvh_selftest runs it on the CPU against brute force, so the culling logic is
+// covered by the CPU test suite.  Kernels and everything that touches LDS stay device-only.
+#define RTX_HD __host__ __device__ __forceinline__
+RTX_HD uint32_t bits_of(float f) { return __builtin_bit_cast(uint32_t, f); }
+
 // Scene records are read-only for the lifetime of a launch.  Reading the wave-uniform ones
 // (the shape / node being tested by the whole wave) through the constant address space makes
 // hipcc emit scalar loads (s_load) into SGPRs instead of 64 identical vector loads.
@@ -157,11 +163,11 @@ struct Params {
 
 // ------------------------------------------------------------------------ f32 math
 
-__device__ __forceinline__ V4 v4(float x, float y, float z, float w) { return V4{x, y, z, w}; }
-__device__ __forceinline__ V4 add(V4 a, V4 b) { return v4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
-__device__ __forceinline__ V4 sub(V4 a, V4 b) { return v4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
-__device__ __forceinline__ V4 muls(V4 a, float s) { return v4(a.x * s, a.y * s, a.z * s, a.w * s); }
-__device__ __forceinline__ V4 neg(V4 a) { return v4(-a.x, -a.y, -a.z, -a.w); }
+RTX_HD V4 v4(float x, float y, float z, float w) { return V4{x, y, z, w}; }
+RTX_HD V4 add(V4 a, V4 b) { return v4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+RTX_HD V4 sub(V4 a, V4 b) { return v4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+RTX_HD V4 muls(V4 a, float s) { return v4(a.x * s, a.y * s, a.z * s, a.w * s); }
+RTX_HD V4 neg(V4 a) { return v4(-a.x, -a.y, -a.z, -a.w); }
 
 // The template flag C ("canonical") marks kernels for scenes in which every point carries
 // w == 1 and every vector w == 0 exactly: all shape inverses, the camera inverse and the light
@@ -174,44 +180,44 @@ __device__ __forceinline__ V4 neg(V4 a) { return v4(-a.x, -a.y, -a.z, -a.w); }
 
 // tup.dot — four lanes, left to right (src/tuple.zig:38-40)
 template <bool C>
-__device__ __forceinline__ float dot(V4 u, V4 v) {
+RTX_HD float dot(V4 u, V4 v) {
     const float s = u.x * v.x + u.y * v.y + u.z * v.z;
     return C ? s : s + u.w * v.w;
 }
 template <bool C>
-__device__ __forceinline__ float magnitude(V4 v) { return sqrtf(dot<C>(v, v)); }  // tuple.zig:50-52
+RTX_HD float magnitude(V4 v) { return sqrtf(dot<C>(v, v)); }  // tuple.zig:50-52
 template <bool C>
-__device__ __forceinline__ V4 normalize(V4 v) {                                   // tuple.zig:54-56
+RTX_HD V4 normalize(V4 v) {                                   // tuple.zig:54-56
     const float m = magnitude<C>(v);
     return v4(v.x / m, v.y / m, v.z / m, C ? 0.0f : v.w / m);
 }
 template <bool C>
-__device__ __forceinline__ V4 reflect(V4 incident, V4 normal) {                   // tuple.zig:58-77
+RTX_HD V4 reflect(V4 incident, V4 normal) {                   // tuple.zig:58-77
     return sub(incident, muls(muls(normal, dot<C>(incident, normal)), 2.0f));
 }
 
 // mat.mulTuple (src/matrix.zig:62-64) with a row-major 16-float matrix.
-__device__ __forceinline__ V4 mul_mat(const float* m, V4 b) {
+RTX_HD V4 mul_mat(const float* m, V4 b) {
     return v4(m[0] * b.x + m[1] * b.y + m[2] * b.z + m[3] * b.w, m[4] * b.x + m[5] * b.y + m[6] * b.z + m[7] * b.w,
               m[8] * b.x + m[9] * b.y + m[10] * b.z + m[11] * b.w,
               m[12] * b.x + m[13] * b.y + m[14] * b.z + m[15] * b.w);
 }
 // The same for a point (w == 1 when C) and for a vector (w == 0 when C).
 template <bool C>
-__device__ __forceinline__ V4 mul_point(const float* m, V4 b) {
+RTX_HD V4 mul_point(const float* m, V4 b) {
     if (!C) return mul_mat(m, b);
     return v4(m[0] * b.x + m[1] * b.y + m[2] * b.z + m[3], m[4] * b.x + m[5] * b.y + m[6] * b.z + m[7],
               m[8] * b.x + m[9] * b.y + m[10] * b.z + m[11], 1.0f);
 }
 template <bool C>
-__device__ __forceinline__ V4 mul_dir(const float* m, V4 b) {
+RTX_HD V4 mul_dir(const float* m, V4 b) {
     if (!C) return mul_mat(m, b);
     return v4(m[0] * b.x + m[1] * b.y + m[2] * b.z, m[4] * b.x + m[5] * b.y + m[6] * b.z,
               m[8] * b.x + m[9] * b.y + m[10] * b.z, 0.0f);
 }
 // mat.mul(mat.transpose(m), b) (src/matrix.zig:74-87 then :62-64); b is a normal (w == 0 when C).
 template <bool C>
-__device__ __forceinline__ V4 mul_mat_t(const float* m, V4 b) {
+RTX_HD V4 mul_mat_t(const float* m, V4 b) {
     if (C) return v4(m[0] * b.x + m[4] * b.y + m[8] * b.z, m[1] * b.x + m[5] * b.y + m[9] * b.z,
                      m[2] * b.x + m[6] * b.y + m[10] * b.z, 0.0f);
     return v4(m[0] * b.x + m[4] * b.y + m[8] * b.z + m[12] * b.w, m[1] * b.x + m[5] * b.y + m[9] * b.z + m[13] * b.w,
@@ -249,7 +255,7 @@ struct Closest {
 template <bool TRACK>
 struct ClosestVisitor {
     Closest c;
-    __device__ __forceinline__ void init() {
+    RTX_HD void init() {
         c.t = 0.0f;
         c.idx = kNone;
         c.pred_t = 0.0f;
@@ -259,14 +265,14 @@ struct ClosestVisitor {
     // The world/group walk offers shapes in insertion order (ORDERED): a strict compare is
     // enough there.  The BVH offers triangles in tree order, so it compares the index too.
     template <bool ORDERED>
-    __device__ __forceinline__ void hit(float t, uint32_t s) {
+    RTX_HD void hit(float t, uint32_t s) {
         if (t >= 0.0f && (c.idx == kNone || t < c.t || (!ORDERED && t == c.t && s < c.idx))) {
             c.t = t;
             c.idx = s;
         }
     }
     template <bool ORDERED>
-    __device__ __forceinline__ void pred(float t, uint32_t s) {
+    RTX_HD void pred(float t, uint32_t s) {
         if (TRACK && t < 0.0f &&
             (c.pred_idx == kNone || (ORDERED ? t >= c.pred_t : (t > c.pred_t || (t == c.pred_t && s > c.pred_idx))))) {
             c.pred_t = t;
@@ -278,10 +284,10 @@ struct ClosestVisitor {
     // the mesh triangles is needed by few rays (those that end on a transparent material) and
     // is collected for exactly those by a second walk (PredVisitor, traverse_pred).
     static constexpr bool kBvhPred = false;
-    __device__ __forceinline__ bool done() const { return false; }
+    RTX_HD bool done() const { return false; }
     // Range of t a BVH subtree must overlap to matter: [0, current best].
-    __device__ __forceinline__ float t_lo() const { return 0.0f; }
-    __device__ __forceinline__ float t_hi() const { return c.idx == kNone ? INFINITY : c.t; }
+    RTX_HD float t_lo() const { return 0.0f; }
+    RTX_HD float t_hi() const { return c.idx == kNone ? INFINITY : c.t; }
 };
 
 // The n1 predecessor among BVH triangles: the largest t < 0, ties to the highest insertion
@@ -290,18 +296,18 @@ struct PredVisitor {
     float pred_t;
     uint32_t pred_idx;
     template <bool ORDERED>
-    __device__ __forceinline__ void hit(float, uint32_t) {}
+    RTX_HD void hit(float, uint32_t) {}
     template <bool ORDERED>
-    __device__ __forceinline__ void pred(float t, uint32_t s) {
+    RTX_HD void pred(float t, uint32_t s) {
         if (t < 0.0f && (pred_idx == kNone || t > pred_t || (t == pred_t && s > pred_idx))) {
             pred_t = t;
             pred_idx = s;
         }
     }
     static constexpr bool kBvhPred = true;
-    __device__ __forceinline__ bool done() const { return false; }
-    __device__ __forceinline__ float t_lo() const { return pred_idx == kNone ? -INFINITY : pred_t; }
-    __device__ __forceinline__ float t_hi() const { return 0.0f; }
+    RTX_HD bool done() const { return false; }
+    RTX_HD float t_lo() const { return pred_idx == kNone ? -INFINITY : pred_t; }
+    RTX_HD float t_hi() const { return 0.0f; }
 };
 
 // isShadowed (src/world.zig:97-120): the nearest t >= 0 is < distance  <=>  some root lies
@@ -392,7 +398,7 @@ constexpr uint32_t kShapeIdentity = 1u << 8;  // library-internal: the inverse i
 // Triangle.intersect (src/triangle.zig:32-50, Moller-Trumbore) on the object-space ray.
 // cross() has w = 0, so the w lanes of e0 / e1 / p0_to_origin only ever add an exact zero to
 // the dots; they are left out.
-__device__ __forceinline__ bool triangle_root(V4 ro, V4 rd, const float* p0, const float* e0, const float* e1, float& t) {
+RTX_HD bool triangle_root(V4 ro, V4 rd, const float* p0, const float* e0, const float* e1, float& t) {
     const float cx = rd.y * e1[2] - rd.z * e1[1], cy = rd.z * e1[0] - rd.x * e1[2], cz = rd.x * e1[1] - rd.y * e1[0];
     const float det = e0[0] * cx + e0[1] * cy + e0[2] * cz;
     if (fabsf(det) < kEpsilon) return false;
@@ -543,7 +549,7 @@ __device__ __forceinline__ void intersect_shape(V& v, const RT_CONST rtx_shape& 
 // loop the lanes that sit on a leaf would run the long triangle test while all the others,
 // still walking boxes, idle through it — and the other way round.
 template <bool C, class V>
-__device__ __forceinline__ void traverse_bvh(V& v, const Params& p, uint32_t root, V4 o, V4 d) {
+RTX_HD void traverse_bvh(V& v, const Params& p, uint32_t root, V4 o, V4 d) {
     const float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
     const rtx_bvh::Node* nodes = p.bvh_nodes;
     uint32_t n = root;
@@ -553,7 +559,7 @@ __device__ __forceinline__ void traverse_bvh(V& v, const Params& p, uint32_t roo
         while (tri == tri_end && n < end && !v.done()) {
             const float4 a = *reinterpret_cast<const float4*>(&nodes[n].bmin[0]);
             const float4 b = *reinterpret_cast<const float4*>(&nodes[n].bmax[0]);
-            const uint32_t skip = __float_as_uint(a.w), leaf = __float_as_uint(b.w);
+            const uint32_t skip = bits_of(a.w), leaf = bits_of(b.w);
             // slab test; a NaN (0 * inf) drops out of fmin/fmax like in the reference's checkAxis.
             // Kept as (bound - o) * (1 / d): the contracted form fma(bound, 1/d, -o/d) loses the
             // small difference bound - o against a large o / d and would cull wrongly.
@@ -580,7 +586,7 @@ __device__ __forceinline__ void traverse_bvh(V& v, const Params& p, uint32_t roo
             const float4 q0 = *reinterpret_cast<const float4*>(&tr->p0[0]);
             const float4 q1 = *reinterpret_cast<const float4*>(&tr->e0[0]);
             const float4 q2 = *reinterpret_cast<const float4*>(&tr->e1[0]);
-            const uint32_t shape = __float_as_uint(q0.w), flags = __float_as_uint(q1.w);
+            const uint32_t shape = bits_of(q0.w), flags = bits_of(q1.w);
             V4 ro = o, rd = d;
             if (!(flags & kShapeIdentity)) {
                 const float* inv = p.shapes[shape].inverse;
@@ -1405,6 +1411,33 @@ int validate_desc(const rtx_scene_desc* d) {
     return RTX_OK;
 }
 
+// Library-side derived data: identity flags on the shapes and one BVH per long triangle run of a
+// gate (links in rtx_node.reserved: [0] = root + 1, [1] = shapes still tested linearly).
+// `linear` receives the gates without BVH links (rtx_opts.no_bvh).
+void build_bvhs(std::vector<rtx_shape>& shapes, std::vector<rtx_node>& nodes, std::vector<rtx_node>& linear,
+                std::vector<rtx_bvh::Node>& bvh_nodes, std::vector<rtx_bvh::Tri>& bvh_tris) {
+    static const float kIdentity[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    for (rtx_shape& sh : shapes) {
+        bool ident = true;
+        for (int k = 0; k < 16; ++k) ident = ident && sh.inverse[k] == kIdentity[k];
+        sh.flags &= 0xFFu;  // bits above are the library's
+        if (ident) sh.flags |= kShapeIdentity;
+    }
+    for (rtx_node& n : nodes) n.reserved[0] = n.reserved[1] = 0;
+    linear = nodes;
+    for (rtx_node& n : nodes) {
+        // shapes of a node are in type order, so its triangles are the tail of its range
+        uint32_t n_lin = 0;
+        while (n_lin < n.n_shapes && shapes[n.first_shape + n_lin].type != RTX_TRIANGLE) ++n_lin;
+        const uint32_t n_tri = n.n_shapes - n_lin;
+        if (n_tri < rtx_bvh::kMinTris) continue;
+        const uint32_t root = rtx_bvh::build_run(shapes.data(), n.first_shape + n_lin, n_tri, bvh_nodes, bvh_tris);
+        if (root == rtx_bvh::kNoLeaf) continue;
+        n.reserved[0] = root + 1;
+        n.reserved[1] = n_lin;
+    }
+}
+
 int check_camera(const rtx_camera* cam) {
     if (!cam) return fail(RTX_E_INVALID, "camera is NULL");
     if (cam->horizontal_size == 0 || cam->vertical_size == 0) return fail(RTX_E_INVALID, "empty canvas");
@@ -1753,13 +1786,6 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out) {
     // Library-side derived data: identity flags and one BVH per long triangle run.
     std::vector<rtx_shape> shapes(desc->shapes, desc->shapes + desc->n_shapes);
     std::vector<rtx_node> nodes(desc->nodes, desc->nodes + desc->n_nodes);
-    static const float kIdentity[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
-    for (rtx_shape& sh : shapes) {
-        bool ident = true;
-        for (int k = 0; k < 16; ++k) ident = ident && sh.inverse[k] == kIdentity[k];
-        sh.flags &= 0xFFu;  // bits above are the library's
-        if (ident) sh.flags |= kShapeIdentity;
-    }
     // Canonical w lanes (see dot<C>): affine inverses, untranslated cubes, light at w == 1.
     s->canon = desc->light_position[3] == 1.0f;
     for (const rtx_shape& sh : shapes) {
@@ -1768,21 +1794,10 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out) {
         if (sh.type == RTX_CUBE && !(m[3] == 0.0f && m[7] == 0.0f && m[11] == 0.0f)) s->canon = false;
         if (sh.type == RTX_TRIANGLE && sh.normal[3] != 0.0f) s->canon = false;
     }
-    for (rtx_node& n : nodes) n.reserved[0] = n.reserved[1] = 0;
-    std::vector<rtx_node> linear = nodes;
+    std::vector<rtx_node> linear;
     std::vector<rtx_bvh::Node> bvh_nodes;
     std::vector<rtx_bvh::Tri> bvh_tris;
-    for (rtx_node& n : nodes) {
-        // shapes of a node are in type order, so its triangles are the tail of its range
-        uint32_t n_lin = 0;
-        while (n_lin < n.n_shapes && shapes[n.first_shape + n_lin].type != RTX_TRIANGLE) ++n_lin;
-        const uint32_t n_tri = n.n_shapes - n_lin;
-        if (n_tri < rtx_bvh::kMinTris) continue;
-        const uint32_t root = rtx_bvh::build_run(shapes.data(), n.first_shape + n_lin, n_tri, bvh_nodes, bvh_tris);
-        if (root == rtx_bvh::kNoLeaf) continue;
-        n.reserved[0] = root + 1;
-        n.reserved[1] = n_lin;
-    }
+    build_bvhs(shapes, nodes, linear, bvh_nodes, bvh_tris);
     s->n_bvh_nodes = (uint32_t)bvh_nodes.size();
     s->n_bvh_tris = (uint32_t)bvh_tris.size();
     HIP_TRY_S(upload((void**)&s->d_shapes, shapes.data(), sizeof(rtx_shape) * shapes.size()));
@@ -1874,6 +1889,92 @@ int rtx_render(rtx_scene* s, const rtx_camera* cam, const rtx_opts* opts, float*
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(rgb_out, s->d_canvas, floats * sizeof(float), hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
+    return RTX_OK;
+}
+
+// Host-only check of the triangle BVHs a scene would get (no device needed): structure of every
+// tree, and for n rays the closest hit and the n1 predecessor found by the device's own
+// traversal code (compiled for the host) against brute force over the same triangles.
+int rtx_bvh_selftest(const rtx_scene_desc* desc, const float* origins, const float* directions, uint32_t n,
+                     uint32_t* n_bvh_nodes, uint32_t* n_bvh_tris, uint32_t* mismatches) {
+    int rc = validate_desc(desc);
+    if (rc) return rc;
+    if (n && (!origins || !directions)) return fail(RTX_E_INVALID, "NULL ray buffer");
+    std::vector<rtx_shape> shapes(desc->shapes, desc->shapes + desc->n_shapes);
+    std::vector<rtx_node> nodes(desc->nodes, desc->nodes + desc->n_nodes), linear;
+    std::vector<rtx_bvh::Node> bn;
+    std::vector<rtx_bvh::Tri> bt;
+    build_bvhs(shapes, nodes, linear, bn, bt);
+    if (n_bvh_nodes) *n_bvh_nodes = (uint32_t)bn.size();
+    if (n_bvh_tris) *n_bvh_tris = (uint32_t)bt.size();
+    uint32_t bad = 0;
+    for (const rtx_node& g : nodes) {
+        if (!g.reserved[0]) continue;
+        const uint32_t root = g.reserved[0] - 1u, first_tri = g.first_shape + g.reserved[1], last_tri = g.first_shape + g.n_shapes;
+        const uint32_t end = bn[root].skip;
+        if (end <= root || end > bn.size()) return fail(RTX_E_INVALID, "bvh %u: bad extent", root);
+        // structure: skips move forward and stay inside the parent, every hittable triangle of the run sits in exactly one leaf
+        std::vector<uint32_t> seen(last_tri - first_tri, 0u);
+        for (uint32_t k = root; k < end; ++k) {
+            const rtx_bvh::Node& nd = bn[k];
+            if (nd.skip <= k || nd.skip > end) return fail(RTX_E_INVALID, "bvh node %u: skip %u leaves [%u, %u)", k, nd.skip, root, end);
+            if (nd.leaf == rtx_bvh::kNoLeaf) {
+                if (nd.skip == k + 1u) return fail(RTX_E_INVALID, "bvh node %u: interior node without children", k);
+                continue;
+            }
+            if (nd.skip != k + 1u) return fail(RTX_E_INVALID, "bvh node %u: a leaf with a subtree", k);
+            const uint32_t t0 = nd.leaf >> 3, cnt = nd.leaf & 7u;
+            if ((size_t)t0 + cnt > bt.size()) return fail(RTX_E_INVALID, "bvh node %u: leaf out of range", k);
+            for (uint32_t t = t0; t < t0 + cnt; ++t) {
+                const rtx_bvh::Tri& tr = bt[t];
+                if (tr.shape < first_tri || tr.shape >= last_tri) return fail(RTX_E_INVALID, "bvh leaf %u: foreign triangle %u", k, tr.shape);
+                seen[tr.shape - first_tri]++;
+                if (std::memcmp(tr.p0, shapes[tr.shape].p0, 12) || std::memcmp(tr.e0, shapes[tr.shape].e0, 12) ||
+                    std::memcmp(tr.e1, shapes[tr.shape].e1, 12) || tr.flags != shapes[tr.shape].flags)
+                    return fail(RTX_E_INVALID, "bvh leaf %u: triangle %u differs from its shape", k, tr.shape);
+            }
+        }
+        for (uint32_t t = first_tri; t < last_tri; ++t) {
+            const rtx_shape& sh = shapes[t];
+            const bool degenerate = sh.e0[0] == 0.0f && sh.e0[1] == 0.0f && sh.e0[2] == 0.0f && sh.e0[3] == 0.0f;
+            if (seen[t - first_tri] != (degenerate ? 0u : 1u)) return fail(RTX_E_INVALID, "triangle %u sits in %u leaves", t, seen[t - first_tri]);
+        }
+        // rays: the traversal (closest hit, then the predecessor walk) against brute force
+        Params p;
+        std::memset(&p, 0, sizeof p);
+        p.shapes = shapes.data();
+        p.bvh_nodes = bn.data();
+        p.bvh_tris = bt.data();
+        for (uint32_t r = 0; r < n; ++r) {
+            const V4 o = v4(origins[4 * r], origins[4 * r + 1], origins[4 * r + 2], origins[4 * r + 3]);
+            const V4 d = v4(directions[4 * r], directions[4 * r + 1], directions[4 * r + 2], directions[4 * r + 3]);
+            ClosestVisitor<true> cv;
+            cv.init();
+            traverse_bvh<false>(cv, p, root, o, d);
+            PredVisitor pv{0.0f, kNone};
+            traverse_bvh<false>(pv, p, root, o, d);
+            ClosestVisitor<true> ref;
+            ref.init();
+            PredVisitor pref{0.0f, kNone};
+            for (uint32_t t = first_tri; t < last_tri; ++t) {
+                const rtx_shape& sh = shapes[t];
+                V4 ro = o, rd = d;
+                if (!(sh.flags & kShapeIdentity)) {
+                    ro = mul_point<false>(sh.inverse, o);
+                    rd = mul_dir<false>(sh.inverse, d);
+                }
+                float tt;
+                if (triangle_root(ro, rd, sh.p0, sh.e0, sh.e1, tt)) {
+                    ref.hit<false>(tt, t);
+                    if (!(sh.flags & RTX_SHAPE_N1_INVISIBLE)) pref.pred<false>(tt, t);
+                }
+            }
+            const bool same_hit = cv.c.idx == ref.c.idx && (cv.c.idx == kNone || bits_of(cv.c.t) == bits_of(ref.c.t));
+            const bool same_pred = pv.pred_idx == pref.pred_idx && (pv.pred_idx == kNone || bits_of(pv.pred_t) == bits_of(pref.pred_t));
+            if (!same_hit || !same_pred) ++bad;
+        }
+    }
+    if (mismatches) *mismatches = bad;
     return RTX_OK;
 }
 
