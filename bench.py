@@ -127,6 +127,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-events", action="store_true", help="experiment: no per-launch HIP events in the timed loop")
+    ap.add_argument("--overlap-frames", action="store_true",
+                    help="render the two frames of a step on two streams (+6 %% throughput; per-kernel profiles no longer isolated)")
     ap.add_argument("--split-frames", action="store_true",
                     help="N > 1: split every frame into strips across the ranks (strong scaling) instead of dealing whole frames")
     args = ap.parse_args()
@@ -155,11 +157,12 @@ def main():
     tstream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(tstream)
     stream = tstream.cuda_stream
-    # The two frames of a step are independent: the second scene renders on a stream of its own,
-    # so its kernels fill the tails (and the empty deep levels) of the first one's (+7 %).  Steps
-    # that carry per-launch events stay on one stream: their durations are those of each kernel
-    # running alone.  RTX_BENCH_ONE_STREAM=1 switches the overlap off.
-    side = None if os.environ.get("RTX_BENCH_ONE_STREAM") == "1" else torch.cuda.Stream(device=dev)
+    # --overlap-frames: the two frames of a step are independent, so the second scene can render on
+    # a stream of its own and its kernels fill the tails (and the empty deep levels) of the first
+    # one's: +6 % Mrays/s.  Off by default: overlapped kernels stretch each other, and the
+    # per-kernel durations of `rocprofv3 --kernel-trace --stats` over this command (profiles/)
+    # would no longer be those of the kernel running alone, which is what the roofline uses.
+    side = torch.cuda.Stream(device=dev) if args.overlap_frames else None
 
     samples = [rta.Sample(name, WIDTH, HEIGHT) for name in SCENES]
     scenes = [rta.Scene(s.world, device=dev.index) for s in samples]
@@ -224,9 +227,8 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         # Per-launch HIP events cost ~14 % of the step when every launch is bracketed (they break
-        # the back-to-back dispatch), so every EVENT_EVERY-th timed step carries them (and runs
-        # its two frames one after the other, see `side`).
-        frame(k, not args.no_events and k % EVENT_EVERY == 0)
+        # the back-to-back dispatch), so every EVENT_EVERY-th timed step carries them.
+        frame(k, not args.no_events and k % EVENT_EVERY == EVENT_EVERY // 2)
     fence()
     dt = time.perf_counter() - t0
 
@@ -255,7 +257,7 @@ def main():
         launches = sum(p.launches_trace_shade for p in prof)
         flops_step = sum(trace_shade_flops(s.world, st) for s, st in zip(samples, stats))
         avg_ms = ms_trace / max(launches, 1)
-        profiled_steps = len(range(0, args.steps, EVENT_EVERY))
+        profiled_steps = len(range(EVENT_EVERY // 2, args.steps, EVENT_EVERY))
         flops_per_launch = flops_step * profiled_steps / max(launches, 1)
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         traffic, traffic_src = measured_traffic() if n == 1 else (None, None)  # the PMC pass is of whole frames
@@ -288,8 +290,7 @@ def main():
                 "flops_per_launch": flops_per_launch, "avg_launch_ms": avg_ms, "launches": launches,
                 "share_of_step": (ms_trace / profiled_steps) / (dt / args.steps * 1e3) if dt > 0 and profiled_steps else None,
                 "note": "f32 VALU roofline (no MFMA: divergent per-lane scalar math); peak = non-FMA issue rate; "
-                        "rank 0's launches of every %d-th timed step, bracketed by HIP events on the render stream "
-                        "(those steps render their two frames back to back, the others overlap them on two streams); "
+                        "rank 0's launches of every %d-th timed step, bracketed by HIP events on the render stream; "
                         "traffic = HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE) from the committed PMC pass "
                         "named in traffic_source" % EVENT_EVERY,
             },
