@@ -95,11 +95,12 @@ __device__ __forceinline__ const RT_CONST T* as_const(const T* p) {
 constexpr uint32_t kShards = 64;
 
 struct ShardCounters {  // one 128-byte line per shard
-    // per level d: low 32 bits = rays queued for level d + 1, high 32 bits = interior nodes at d
+    // per level d: low 32 bits = reflected rays queued for level d + 1, high 32 bits = interior nodes at d
     unsigned long long alloc[kLevels];
     unsigned long long hit_kinds;  // low 32: hits on patterned materials, high 32: on transparent ones
     uint32_t hits[kLevels];        // hits at level d == isShadowed calls
-    uint32_t pad[32 - 2 * kLevels - 2 - kLevels];
+    uint32_t refr[kLevels];        // per level d: refracted rays queued for level d + 1 (their own region)
+    uint32_t pad[32 - 2 * kLevels - 2 - kLevels - kLevels];
 };
 static_assert(sizeof(ShardCounters) == 128, "one cache line per shard");
 
@@ -793,15 +794,24 @@ __device__ __forceinline__ Color combine(Color surface, Color reflected, Color r
 // Slots for this wave's interior nodes and child rays with ONE returning atomic: the shard's
 // per-level word packs (nodes << 32) | rays.  Returns the shard-local bases.
 struct WaveAlloc {
-    uint32_t ray_base, node_base;
+    uint32_t refl_base, refr_base, node_base;
 };
-__device__ __forceinline__ WaveAlloc wave_alloc(unsigned long long* word, uint32_t n_rays, uint32_t n_nodes) {
-    WaveAlloc a{0u, 0u};
-    if (n_rays == 0u && n_nodes == 0u) return a;  // wave-uniform
+// Reflected and refracted children go to separate regions of the shard's queue (reflected from
+// the bottom up, refracted from the top down): a wave of the next level then reads rays of one
+// kind only — rays that left a surface and rays that entered it meet different shapes and
+// materials, and mixed in one wave they would serialise each other's shading branches.
+__device__ __forceinline__ WaveAlloc wave_alloc(ShardCounters* sc, uint32_t level, uint32_t n_refl, uint32_t n_refr, uint32_t n_nodes) {
+    WaveAlloc a{0u, 0u, 0u};
+    if (n_refl == 0u && n_refr == 0u && n_nodes == 0u) return a;  // wave-uniform
     unsigned long long old = 0ull;
-    if (__lane_id() == 0u) old = atomicAdd(word, (static_cast<unsigned long long>(n_nodes) << 32) | n_rays);
-    a.ray_base = __shfl(static_cast<uint32_t>(old), 0);
+    uint32_t old_refr = 0u;
+    if (__lane_id() == 0u) {
+        if (n_refl != 0u || n_nodes != 0u) old = atomicAdd(&sc->alloc[level], (static_cast<unsigned long long>(n_nodes) << 32) | n_refl);
+        if (n_refr != 0u) old_refr = atomicAdd(&sc->refr[level], n_refr);
+    }
+    a.refl_base = __shfl(static_cast<uint32_t>(old), 0);
     a.node_base = __shfl(static_cast<uint32_t>(old >> 32), 0);
+    a.refr_base = __shfl(old_refr, 0);
     return a;
 }
 
@@ -917,19 +927,28 @@ __attribute__((amdgpu_waves_per_eu((BVH || !C) ? RTX_WAVES_PER_EU : RTX_WAVES_PE
 
     // Level 0 walks all items (wave w takes chunks w, w + n_waves, ...; chunk c belongs to
     // shard c % kShards); deeper levels walk this wave's shard.
-    uint32_t count, first, stride, in_base;
+    // Deeper levels: the shard's region holds reflected rays [0, n_refl_in) from its bottom and
+    // refracted rays from its top down; chunks of 64 cover first the one, then the other.
+    uint32_t count, first, stride, in_base, n_refl_in = 0u, n_refr_in = 0u, refl_span = 0u, in_top = 0u;
     if (root) {
         count = GEN ? p.tiles_x * ((p.n_rows + 7u) / 8u) * 64u : p.root_count;
         first = wave * 64u;
         stride = n_waves * 64u;
         in_base = 0u;
     } else {
-        count = static_cast<uint32_t>(sc->alloc[level - 1]);
+        n_refl_in = static_cast<uint32_t>(sc->alloc[level - 1]);
+        n_refr_in = sc->refr[level - 1];
+        refl_span = (n_refl_in + 63u) & ~63u;
+        count = refl_span + ((n_refr_in + 63u) & ~63u);
         first = (wave / kShards) * 64u;
         stride = (n_waves / kShards) * 64u;
-        in_base = shard * (p.shard_cap0 << (level * p.level_shift));
+        const uint32_t cap_in = p.shard_cap0 << (level * p.level_shift);
+        in_base = shard * cap_in;
+        in_top = in_base + cap_in - 1u;
     }
-    const uint32_t out_base = shard * (p.shard_cap0 << ((level + 1u) * p.level_shift));
+    const uint32_t cap_out = p.shard_cap0 << ((level + 1u) * p.level_shift);
+    const uint32_t out_base = shard * cap_out;
+    const uint32_t out_top = out_base + cap_out - 1u;
     const uint32_t node_base = p.node_off[level] + shard * (p.shard_cap0 << (level * p.level_shift));
 
     uint32_t local_hits = 0, local_patterned = 0, local_transparent = 0;
@@ -961,24 +980,32 @@ __attribute__((amdgpu_waves_per_eu((BVH || !C) ? RTX_WAVES_PER_EU : RTX_WAVES_PE
             o = mul_mat(p.cam_inv, v4(0.0f, 0.0f, 0.0f, 1.0f));
             d = normalize<C>(sub(pixel, o));
             link = (p.compact_rows ? lrow : py) * p.width + px;
-        } else if (on) {
-            const float4 qo4 = p.q_org[qi][in_base + i];
-            const float4 qd4 = p.q_dir[qi][in_base + i];
-            if (C) {
-                o = v4(qo4.x, qo4.y, qo4.z, 1.0f);
-                d = v4(qd4.x, qd4.y, qd4.z, 0.0f);
-                link = __float_as_uint(qo4.w);
-                weight = qd4.w;
-            } else {
-                const uint2 ql = p.q_link[qi][in_base + i];
-                o = v4(qo4.x, qo4.y, qo4.z, qo4.w);
-                d = v4(qd4.x, qd4.y, qd4.z, qd4.w);
-                link = ql.x;
-                weight = __uint_as_float(ql.y);
-            }
         } else {
-            o = v4(0.0f, 0.0f, 0.0f, 1.0f);
-            d = v4(0.0f, 0.0f, 1.0f, 0.0f);
+            uint32_t at = i;  // level 0 of rtx_color_at: one region from slot 0
+            if (!root) {
+                const bool in_refl = base < refl_span;  // wave-uniform
+                on = in_refl ? (i < n_refl_in) : (i - refl_span < n_refr_in);
+                at = in_refl ? in_base + i : in_top - (i - refl_span);
+            }
+            if (on) {
+                const float4 qo4 = p.q_org[qi][at];
+                const float4 qd4 = p.q_dir[qi][at];
+                if (C) {
+                    o = v4(qo4.x, qo4.y, qo4.z, 1.0f);
+                    d = v4(qd4.x, qd4.y, qd4.z, 0.0f);
+                    link = __float_as_uint(qo4.w);
+                    weight = qd4.w;
+                } else {
+                    const uint2 ql = p.q_link[qi][at];
+                    o = v4(qo4.x, qo4.y, qo4.z, qo4.w);
+                    d = v4(qd4.x, qd4.y, qd4.z, qd4.w);
+                    link = ql.x;
+                    weight = __uint_as_float(ql.y);
+                }
+            } else {
+                o = v4(0.0f, 0.0f, 0.0f, 1.0f);
+                d = v4(0.0f, 0.0f, 1.0f, 0.0f);
+            }
         }
 
         DIAG_PHASE(0);  // ray fetch / generation
@@ -1080,7 +1107,7 @@ __attribute__((amdgpu_waves_per_eu((BVH || !C) ? RTX_WAVES_PER_EU : RTX_WAVES_PE
         const unsigned long long below = (1ull << lane) - 1ull;
         const uint32_t n_refl = __popcll(m_refl);
         DIAG_PHASE(5);  // leaf delivery
-        const WaveAlloc wa = wave_alloc(&sc->alloc[level], n_refl + __popcll(m_refr), __popcll(m_node));
+        const WaveAlloc wa = wave_alloc(sc, level, n_refl, __popcll(m_refr), __popcll(m_node));
         DIAG_PHASE(6);  // slot allocation (the atomic)
         uint32_t node = 0;
         if (interior) {
@@ -1093,13 +1120,13 @@ __attribute__((amdgpu_waves_per_eu((BVH || !C) ? RTX_WAVES_PER_EU : RTX_WAVES_PE
             if (!spawn_refract) p.node_c[node] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
         if (spawn_reflect) {
-            const uint32_t slot = out_base + wa.ray_base + __popcll(m_refl & below);
+            const uint32_t slot = out_base + wa.refl_base + __popcll(m_refl & below);
             p.q_org[qo][slot] = make_float4(over_point.x, over_point.y, over_point.z, C ? __uint_as_float(node) : over_point.w);
             p.q_dir[qo][slot] = make_float4(reflectv.x, reflectv.y, reflectv.z, C ? reflective : reflectv.w);
             if (!C) p.q_link[qo][slot] = make_uint2(node, __float_as_uint(reflective));
         }
         if (spawn_refract) {
-            const uint32_t slot = out_base + wa.ray_base + n_refl + __popcll(m_refr & below);
+            const uint32_t slot = out_top - (wa.refr_base + __popcll(m_refr & below));
             p.q_org[qo][slot] =
                 make_float4(under_point.x, under_point.y, under_point.z, C ? __uint_as_float(node | kLinkSlotBit) : under_point.w);
             p.q_dir[qo][slot] = make_float4(refract_dir.x, refract_dir.y, refract_dir.z, C ? transparency : refract_dir.w);
@@ -1152,11 +1179,12 @@ __global__ void k_accumulate(Counters* c, Totals* t, uint32_t level0_rays, uint3
 #pragma unroll
     for (int l = 0; l < kLevels; ++l) {
         const unsigned long long a = sc->alloc[l];
-        rays[l] = (static_cast<uint32_t>(l) <= depth) ? static_cast<uint32_t>(a) : 0u;
+        rays[l] = (static_cast<uint32_t>(l) <= depth) ? static_cast<unsigned long long>(static_cast<uint32_t>(a)) + sc->refr[l] : 0ull;
         nodes += (static_cast<uint32_t>(l) <= depth) ? (a >> 32) : 0ull;
         hits[l] = sc->hits[l];
         sc->alloc[l] = 0ull;
         sc->hits[l] = 0u;
+        sc->refr[l] = 0u;
     }
     patterned = static_cast<uint32_t>(sc->hit_kinds);
     transparent = sc->hit_kinds >> 32;
