@@ -1258,6 +1258,7 @@ struct rtx_scene {
     bool can_spawn = false;  // some material is reflective or transparent: child rays exist
     bool canon = false;      // the scene keeps w == 1 / w == 0 exact (see dot<C>)
     bool two_children = false;  // some material is reflective AND transparent: a hit may spawn two rays
+    bool finite_schlick = true;  // every refractive index is finite and > 0: schlick() cannot return inf / NaN
     float light_position[4];
     float light_intensity[3];
 
@@ -1397,7 +1398,12 @@ TraceKernel trace_kernel(bool track, bool lds, bool canon, bool bvh) {
 
 template <bool GEN>
 void launch_trace(const rtx_scene* s, const Params& p, uint32_t level, uint32_t blocks, hipStream_t st) {
-    hipLaunchKernelGGL(trace_kernel<GEN>(s->track_n1, p.lds_bytes != 0, p.canon != 0, p.has_bvh != 0), dim3(blocks), dim3(256), p.lds_bytes, st, p, level);
+    // At the depth limit (remaining == 0) nothing refracts (src/world.zig:151) and the Schlick
+    // reflectance only weighs two black children (src/world.zig:71-78), so n1 is dead there —
+    // provided the reflectance is finite (0 * R must be 0): s->finite_schlick.  The last level
+    // holds the most rays and runs the kernel without predecessor tracking.
+    const bool track = s->track_n1 && !(level == p.depth && s->finite_schlick);
+    hipLaunchKernelGGL(trace_kernel<GEN>(track, p.lds_bytes != 0, p.canon != 0, p.has_bvh != 0), dim3(blocks), dim3(256), p.lds_bytes, st, p, level);
 }
 
 // Resident 256-thread blocks per CU of a variant (registers and LDS decide).
@@ -1803,6 +1809,7 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out) {
         if (m.transparency != 0.0f) s->track_n1 = true;
         if (m.transparency != 0.0f || m.reflective != 0.0f) s->can_spawn = true;
         if (m.transparency != 0.0f && m.reflective != 0.0f) s->two_children = true;
+        if (!(m.refractive_index > 0.0f && m.refractive_index < INFINITY)) s->finite_schlick = false;
     }
 
     auto upload = [&](void** dst, const void* src, size_t bytes) -> hipError_t {
