@@ -161,7 +161,7 @@ typedef struct rtx_stats {
     uint64_t nodes;          /* interior ray-tree nodes stored for the combine pass */
     uint64_t level_hits[6];  /* hits per depth level (each one is an isShadowed call) */
     uint64_t hits_patterned; /* hits whose material has a pattern (Pattern.atShape evaluated) */
-    uint64_t hits_transparent; /* hits on transparency != 0 (refraction set-up evaluated) */
+    uint64_t hits_transparent; /* hits on transparency != 0 above the depth limit (refraction set-up evaluated) */
     float    ms_total;       /* device time of the whole call (HIP events on the render stream) */
     float    ms_trace_shade; /* sum over launches of the trace+shade kernel (profile=1) */
     float    ms_combine;     /* sum over launches of the combine kernel (profile=1) */

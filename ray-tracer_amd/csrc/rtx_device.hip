@@ -131,6 +131,7 @@ struct Params {
     uint32_t track_n1;  // scene has a transparent material: track the n1 predecessor
     uint32_t canon;     // this frame runs the canonical-w kernels (ray records are 32 bytes)
     uint32_t has_bvh;   // some gate node of `nodes` carries a triangle BVH
+    uint32_t finite_schlick;  // every refractive index is finite and > 0 (schlick() is finite)
     uint32_t depth;
     float light_position[4];
     float light_intensity[3];
@@ -1070,7 +1071,7 @@ __attribute__((amdgpu_waves_per_eu((BVH || !C) ? RTX_WAVES_PER_EU : RTX_WAVES_PE
             reflective = m.reflective;
             transparency = m.transparency;
             local_patterned += m.pattern >= 0 ? 1u : 0u;
-            local_transparent += m.transparency != 0.0f ? 1u : 0u;
+            local_transparent += (m.transparency != 0.0f && remaining != 0u) ? 1u : 0u;  // refraction set-up evaluated
             // shadeHitInternal (src/world.zig:54-79): Phong is evaluated at over_point.
             surface = lighting<C>(p, tab.patterns, m, sh, over_point, eye, normal, sv.found);
             // reflectedColorInternal (src/world.zig:126-143)
@@ -1089,7 +1090,10 @@ __attribute__((amdgpu_waves_per_eu((BVH || !C) ? RTX_WAVES_PER_EU : RTX_WAVES_PE
             }
             if (m.reflective > 0.0f && m.transparency > 0.0f) {
                 use_schlick = true;
-                reflectance = schlick<C>(n1, n2, eye, normal);
+                // At the depth limit the reflectance only weighs two black children: 0 * R and
+                // 0 * (1 - R) are 0 for any finite R, so a scene whose Schlick values are all
+                // finite (p.finite_schlick) need not evaluate it there.
+                if (remaining != 0u || !p.finite_schlick) reflectance = schlick<C>(n1, n2, eye, normal);
             }
         }
 
@@ -1486,6 +1490,7 @@ void fill_scene_params(const rtx_scene* s, Params& p, uint32_t depth) {
     p.bvh_nodes = s->d_bvh_nodes;
     p.bvh_tris = s->d_bvh_tris;
     p.has_bvh = s->n_bvh_nodes ? 1u : 0u;
+    p.finite_schlick = s->finite_schlick ? 1u : 0u;
     p.materials = s->d_materials;
     p.patterns = s->d_patterns;
     p.n_nodes = s->n_nodes;
