@@ -1242,6 +1242,7 @@ struct WorkSet {
     uint2* node_d = nullptr;
     Counters* d_counters = nullptr;
     Totals* d_totals = nullptr;
+    bool counters_dirty = true;    // d_counters are not known to be zero (see run_levels)
     hipStream_t stream = nullptr;  // lane stream (lane 0 of a single-lane frame runs on the caller's)
     hipEvent_t done = nullptr;
 };
@@ -1530,8 +1531,12 @@ int collect_profile(rtx_scene* s, rtx_stats* out) {
 // Run the levels for one batch whose level-0 rays are either generated (GEN) or already in
 // queue 0 (rtx_color_at).
 template <bool GEN>
-int run_levels(rtx_scene* s, const WorkSet& w, Params& p, uint32_t pixels, uint32_t level0_items, hipStream_t st, bool prof,
+int run_levels(rtx_scene* s, WorkSet& w, Params& p, uint32_t pixels, uint32_t level0_items, hipStream_t st, bool prof,
                bool first) {
+    // k_accumulate leaves the shard counters at zero for the next batch; they are cleared here
+    // only when that did not happen (fresh buffers, or an earlier batch that failed half way).
+    if (w.counters_dirty) HIP_TRY(hipMemsetAsync(w.d_counters, 0, sizeof(Counters), st));
+    w.counters_dirty = true;
     bind_work(p, w);
     p.shard_cap0 = w.shard_cap0;
     p.level_shift = s->two_children ? 1u : 0u;
@@ -1593,6 +1598,7 @@ int run_levels(rtx_scene* s, const WorkSet& w, Params& p, uint32_t pixels, uint3
     hipLaunchKernelGGL(k_accumulate, dim3(1), dim3(kShards), 0, st, w.d_counters, w.d_totals, level0_items ? pixels : 0u, last_level,
                        first ? 1u : 0u);
     HIP_TRY(hipGetLastError());
+    w.counters_dirty = false;
     return RTX_OK;
 }
 
@@ -1682,9 +1688,6 @@ int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_opts* opts, float
         HIP_TRY(hipEventRecord(s->ev_fork, st));
         for (int l = 0; l < lanes; ++l) HIP_TRY(hipStreamWaitEvent(lane_stream[l], s->ev_fork, 0));
     }
-    // The shard counters are left at zero by k_accumulate; clear them anyway in case an earlier
-    // call on this scene stopped half way.
-    for (int l = 0; l < lanes; ++l) HIP_TRY(hipMemsetAsync(s->ws[l].d_counters, 0, sizeof(Counters), lane_stream[l]));
 
     uint32_t batch = 0;
     for (uint32_t row0 = 0; row0 < plan.rows_local; row0 += rows_per_batch, ++batch) {
@@ -2053,7 +2056,6 @@ int rtx_color_at(rtx_scene* s, const float* origins, const float* directions, ui
         HIP_TRY(hipMemcpyAsync(w.q_dir[0], directions, (size_t)n * 16, hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemcpyAsync(w.q_link[0], links.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
     }
-    HIP_TRY(hipMemsetAsync(w.d_counters, 0, sizeof(Counters), st));
     Params p;
     fill_scene_params(s, p, depth);
     p.canon = canon ? 1u : 0u;
