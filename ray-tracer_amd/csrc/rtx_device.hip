@@ -871,7 +871,7 @@ __device__ unsigned long long g_diag[16];
 // pattern are per-lane lookups (normalAt, lighting, n1/n2); from global memory each is a
 // dependent L2 round trip per lane and the diagnostic build showed 65 % of the kernel waiting
 // on them, so scenes whose tables fit kLdsSceneBytes are copied into LDS once per block.
-constexpr uint32_t kLdsSceneBytes = 32768;  // 4 blocks per CU keep 128 KB of the 160 KB
+constexpr uint32_t kLdsSceneBytes = 32768;  // 5 blocks per CU (the mesh kernels' occupancy) fill the 160 KB exactly
 
 struct LdsScene {
     const rtx_shape* shapes;
