@@ -491,3 +491,24 @@ def test_two_lanes_equal_one_lane():
     with pytest.raises(rta.RtxError):
         scene.render(s.camera, lanes=3)
     scene.close()
+
+
+def test_scene_lifecycle_returns_device_memory():
+    import torch
+
+    def cycle():
+        s = rta.Sample("glass_spheres", 512, 256)
+        scene = rta.Scene(s.world)
+        scene.render(s.camera, lanes=2, profile=False)
+        scene.render(s.camera, profile=True)
+        scene.color_at(np.array([[0, 0, -5, 1]], np.float32), np.array([[0, 0, 1, 0]], np.float32))
+        scene.close()
+
+    cycle()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(20):
+        cycle()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 64 << 20, "device memory shrank by %d MiB over 20 scene lifecycles" % ((free0 - free1) >> 20)
