@@ -223,6 +223,10 @@ int rtx_color_at(rtx_scene* scene, const float* origins, const float* directions
 int rtx_bvh_selftest(const rtx_scene_desc* desc, const float* origins, const float* directions, uint32_t n,
                      uint32_t* n_bvh_nodes, uint32_t* n_bvh_tris, uint32_t* mismatches);
 
+/* Box tests and triangle tests made by the closest-hit walks of this thread's last rtx_bvh_selftest
+ * (tree-quality statistics; host only). */
+void rtx_bvh_selftest_work(uint64_t* box_tests, uint64_t* triangle_tests);
+
 const char* rtx_last_error(void);
 
 #pragma GCC visibility pop

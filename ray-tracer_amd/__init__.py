@@ -94,6 +94,7 @@ _SIGNATURES = [
     ("rtx_profile_collect", C.c_int, [C.c_void_p, P(RtxStats)]),
     ("rtx_color_at", C.c_int, [C.c_void_p, P(f32), P(f32), u32, u32, P(f32)]),
     ("rtx_bvh_selftest", C.c_int, [P(RtxSceneDesc), P(f32), P(f32), u32, P(u32), P(u32), P(u32)]),
+    ("rtx_bvh_selftest_work", None, [P(C.c_uint64), P(C.c_uint64)]),
     ("rtx_last_error", C.c_char_p, []),
     ("rt_camera_init", None, [u32, u32, f32, P(f32), P(f32), P(f32), P(st.Camera)]),
     ("rt_ray_for_pixel", None, [P(st.Camera), u32, u32, P(st.Ray)]),

@@ -282,6 +282,8 @@ struct ClosestVisitor {
         }
     }
     static constexpr bool kTrack = TRACK;
+    RTX_HD void visited_node() {}     // statistics hooks of the BVH walk (rtx_bvh_selftest counts with them)
+    RTX_HD void tested_triangle() {}
     // The BVH walk of the closest-hit pass looks ahead of the origin only: a predecessor among
     // the mesh triangles is needed by few rays (those that end on a transparent material) and
     // is collected for exactly those by a second walk (PredVisitor, traverse_pred).
@@ -307,6 +309,8 @@ struct PredVisitor {
         }
     }
     static constexpr bool kBvhPred = true;
+    RTX_HD void visited_node() {}
+    RTX_HD void tested_triangle() {}
     RTX_HD bool done() const { return false; }
     RTX_HD float t_lo() const { return pred_idx == kNone ? -INFINITY : pred_t; }
     RTX_HD float t_hi() const { return 0.0f; }
@@ -325,6 +329,8 @@ struct ShadowVisitor {
     __device__ __forceinline__ void pred(float, uint32_t) {}
     static constexpr bool kTrack = false;
     static constexpr bool kBvhPred = false;
+    __device__ __forceinline__ void visited_node() {}
+    __device__ __forceinline__ void tested_triangle() {}
     __device__ __forceinline__ bool done() const { return found; }
     __device__ __forceinline__ float t_lo() const { return 0.0f; }
     __device__ __forceinline__ float t_hi() const { return distance; }
@@ -562,6 +568,7 @@ RTX_HD void traverse_bvh(V& v, const Params& p, uint32_t root, V4 o, V4 d) {
             const float4 a = *reinterpret_cast<const float4*>(&nodes[n].bmin[0]);
             const float4 b = *reinterpret_cast<const float4*>(&nodes[n].bmax[0]);
             const uint32_t skip = bits_of(a.w), leaf = bits_of(b.w);
+            v.visited_node();
             // slab test; a NaN (0 * inf) drops out of fmin/fmax like in the reference's checkAxis.
             // Kept as (bound - o) * (1 / d): the contracted form fma(bound, 1/d, -o/d) loses the
             // small difference bound - o against a large o / d and would cull wrongly.
@@ -589,6 +596,7 @@ RTX_HD void traverse_bvh(V& v, const Params& p, uint32_t root, V4 o, V4 d) {
             const float4 q1 = *reinterpret_cast<const float4*>(&tr->e0[0]);
             const float4 q2 = *reinterpret_cast<const float4*>(&tr->e1[0]);
             const uint32_t shape = bits_of(q0.w), flags = bits_of(q1.w);
+            v.tested_triangle();
             V4 ro = o, rd = d;
             if (!(flags & kShapeIdentity)) {
                 const float* inv = p.shapes[shape].inverse;
@@ -1935,6 +1943,15 @@ int rtx_render(rtx_scene* s, const rtx_camera* cam, const rtx_opts* opts, float*
     return RTX_OK;
 }
 
+thread_local uint64_t g_selftest_nodes = 0, g_selftest_tris = 0;  // work of the last rtx_bvh_selftest's closest-hit walks
+
+// Closest-hit visitor that also counts the work of the walk (host statistics only).
+struct CountingVisitor : ClosestVisitor<true> {
+    uint64_t nodes = 0, tris = 0;
+    void visited_node() { ++nodes; }
+    void tested_triangle() { ++tris; }
+};
+
 // Host-only check of the triangle BVHs a scene would get (no device needed): structure of every
 // tree, and for n rays the closest hit and the n1 predecessor found by the device's own
 // traversal code (compiled for the host) against brute force over the same triangles.
@@ -1948,6 +1965,7 @@ int rtx_bvh_selftest(const rtx_scene_desc* desc, const float* origins, const flo
     std::vector<rtx_bvh::Node> bn;
     std::vector<rtx_bvh::Tri> bt;
     build_bvhs(shapes, nodes, linear, bn, bt);
+    g_selftest_nodes = g_selftest_tris = 0;
     if (n_bvh_nodes) *n_bvh_nodes = (uint32_t)bn.size();
     if (n_bvh_tris) *n_bvh_tris = (uint32_t)bt.size();
     uint32_t bad = 0;
@@ -1991,9 +2009,11 @@ int rtx_bvh_selftest(const rtx_scene_desc* desc, const float* origins, const flo
         for (uint32_t r = 0; r < n; ++r) {
             const V4 o = v4(origins[4 * r], origins[4 * r + 1], origins[4 * r + 2], origins[4 * r + 3]);
             const V4 d = v4(directions[4 * r], directions[4 * r + 1], directions[4 * r + 2], directions[4 * r + 3]);
-            ClosestVisitor<true> cv;
+            CountingVisitor cv;
             cv.init();
             traverse_bvh<false>(cv, p, root, o, d);
+            g_selftest_nodes += cv.nodes;
+            g_selftest_tris += cv.tris;
             PredVisitor pv{0.0f, kNone};
             traverse_bvh<false>(pv, p, root, o, d);
             ClosestVisitor<true> ref;
@@ -2019,6 +2039,12 @@ int rtx_bvh_selftest(const rtx_scene_desc* desc, const float* origins, const flo
     }
     if (mismatches) *mismatches = bad;
     return RTX_OK;
+}
+
+// Box tests and triangle tests the closest-hit walks of the last rtx_bvh_selftest on this thread made.
+void rtx_bvh_selftest_work(uint64_t* box_tests, uint64_t* triangle_tests) {
+    if (box_tests) *box_tests = g_selftest_nodes;
+    if (triangle_tests) *triangle_tests = g_selftest_tris;
 }
 
 int rtx_color_at(rtx_scene* s, const float* origins, const float* directions, uint32_t n, uint32_t depth, float* rgb_out) {
