@@ -8,7 +8,8 @@
 // world-space vertices and padded; the device slab test adds its own slack.
 //
 // Layout: "threaded" pre-order array — a node's first child is the next node, `skip` is the
-// index after its subtree — so traversal needs no per-lane stack.
+// index after its subtree — so traversal needs no per-lane stack; eight such arrays per tree,
+// one per octant of the ray direction, so that a stackless walk still goes front to back.
 #pragma once
 
 #include <algorithm>
@@ -135,23 +136,50 @@ inline bool bound_triangle(const rtx_shape& s, uint32_t index, Prim& out) {
     return true;
 }
 
+// Number of threaded layouts per tree: one per octant of the ray direction.  The layouts hold the
+// same nodes and leaves; they differ in which child of an interior node comes first — the one on
+// the side the ray comes from along that node's split axis — so a walk meets the nearer child first
+// and the [t_lo, t_hi] range of the visitor culls the farther one more often.
+constexpr uint32_t kLayouts = 8;
+
+struct TreeNode {
+    Box box;
+    int axis = 0;           // split axis of an interior node
+    int left = -1, right = -1;  // children (left holds the smaller centroids along `axis`), -1 in a leaf
+    uint32_t first_tri = 0, n_tris = 0;  // leaf: triangles [first_tri, first_tri + n_tris) of the Tri array
+};
+
 struct Builder {
-    std::vector<Node>& nodes;
     std::vector<Tri>& tris;
     const rtx_shape* shapes;
     std::vector<Prim> prims;
+    std::vector<TreeNode> tree;
 
     static float down(double x) { return std::nextafter((float)x, -INFINITY); }
     static float up(double x) { return std::nextafter((float)x, INFINITY); }
 
-    void emit_box(Node& n, const Box& b) {
-        for (int k = 0; k < 3; ++k) {
-            n.bmin[k] = down(b.mn[k]);
-            n.bmax[k] = up(b.mx[k]);
+    int make_leaf(const Box& box, size_t lo, size_t hi) {
+        TreeNode n;
+        n.box = box;
+        n.first_tri = (uint32_t)tris.size();
+        n.n_tris = (uint32_t)(hi - lo);
+        for (size_t i = lo; i < hi; ++i) {
+            const rtx_shape& s = shapes[prims[i].shape];
+            Tri t{};
+            for (int k = 0; k < 3; ++k) {
+                t.p0[k] = s.p0[k];
+                t.e0[k] = s.e0[k];
+                t.e1[k] = s.e1[k];
+            }
+            t.shape = prims[i].shape;
+            t.flags = s.flags;
+            tris.push_back(t);
         }
+        tree.push_back(n);
+        return (int)tree.size() - 1;
     }
 
-    void build(size_t lo, size_t hi) {
+    int build(size_t lo, size_t hi) {
         Box box, cbox;
         box.reset();
         cbox.reset();
@@ -159,9 +187,6 @@ struct Builder {
             box.add(prims[i].box);
             cbox.add(prims[i].centroid);
         }
-        const size_t me = nodes.size();
-        nodes.push_back(Node{});
-        emit_box(nodes[me], box);
         const size_t n = hi - lo;
         int axis = 0;
         double ext = -1;
@@ -170,94 +195,103 @@ struct Builder {
                 ext = cbox.mx[k] - cbox.mn[k];
                 axis = k;
             }
+        size_t mid;
         if (n <= kLeafTris || !(ext > 0)) {
             // Leaves hold at most 7 triangles (3 bits); degenerate centroid sets are chunked.
-            if (n <= 7) {
-                nodes[me].leaf = (uint32_t)((tris.size() << 3) | n);
-                for (size_t i = lo; i < hi; ++i) {
-                    const rtx_shape& s = shapes[prims[i].shape];
-                    Tri t{};
-                    for (int k = 0; k < 3; ++k) {
-                        t.p0[k] = s.p0[k];
-                        t.e0[k] = s.e0[k];
-                        t.e1[k] = s.e1[k];
-                    }
-                    t.shape = prims[i].shape;
-                    t.flags = s.flags;
-                    tris.push_back(t);
-                }
-                nodes[me].skip = (uint32_t)nodes.size();
-                return;
-            }
-            const size_t mid = lo + n / 2;
-            nodes[me].leaf = kNoLeaf;
-            build(lo, mid);
-            build(mid, hi);
-            nodes[me].skip = (uint32_t)nodes.size();
-            return;
-        }
-        // Binned SAH on the widest centroid axis.
-        constexpr int kBins = 16;
-        Box bbox[kBins];
-        size_t bcount[kBins] = {0};
-        for (auto& b : bbox) b.reset();
-        const double scale = kBins / ext;
-        auto bin_of = [&](const Prim& p) {
-            int b = (int)((p.centroid[axis] - cbox.mn[axis]) * scale);
-            return b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
-        };
-        for (size_t i = lo; i < hi; ++i) {
-            const int b = bin_of(prims[i]);
-            bbox[b].add(prims[i].box);
-            bcount[b]++;
-        }
-        double best = INFINITY;
-        int best_split = -1;
-        for (int sidx = 1; sidx < kBins; ++sidx) {
-            Box l, r;
-            l.reset();
-            r.reset();
-            size_t nl = 0, nr = 0;
-            for (int b = 0; b < sidx; ++b)
-                if (bcount[b]) {
-                    l.add(bbox[b]);
-                    nl += bcount[b];
-                }
-            for (int b = sidx; b < kBins; ++b)
-                if (bcount[b]) {
-                    r.add(bbox[b]);
-                    nr += bcount[b];
-                }
-            if (!nl || !nr) continue;
-            const double cost = l.area() * (double)nl + r.area() * (double)nr;
-            if (cost < best) {
-                best = cost;
-                best_split = sidx;
-            }
-        }
-        size_t mid;
-        if (best_split < 0) {
+            if (n <= 7) return make_leaf(box, lo, hi);
             mid = lo + n / 2;
-            std::nth_element(prims.begin() + lo, prims.begin() + mid, prims.begin() + hi,
-                             [&](const Prim& a, const Prim& b) { return a.centroid[axis] < b.centroid[axis]; });
         } else {
-            // stable_partition keeps the build deterministic
-            auto it = std::stable_partition(prims.begin() + lo, prims.begin() + hi,
-                                            [&](const Prim& p) { return bin_of(p) < best_split; });
-            mid = (size_t)(it - prims.begin());
+            // Binned SAH on the widest centroid axis.
+            constexpr int kBins = 16;
+            Box bbox[kBins];
+            size_t bcount[kBins] = {0};
+            for (auto& b : bbox) b.reset();
+            const double scale = kBins / ext;
+            auto bin_of = [&](const Prim& p) {
+                int b = (int)((p.centroid[axis] - cbox.mn[axis]) * scale);
+                return b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+            };
+            for (size_t i = lo; i < hi; ++i) {
+                const int b = bin_of(prims[i]);
+                bbox[b].add(prims[i].box);
+                bcount[b]++;
+            }
+            double best = INFINITY;
+            int best_split = -1;
+            for (int sidx = 1; sidx < kBins; ++sidx) {
+                Box l, r;
+                l.reset();
+                r.reset();
+                size_t nl = 0, nr = 0;
+                for (int b = 0; b < sidx; ++b)
+                    if (bcount[b]) {
+                        l.add(bbox[b]);
+                        nl += bcount[b];
+                    }
+                for (int b = sidx; b < kBins; ++b)
+                    if (bcount[b]) {
+                        r.add(bbox[b]);
+                        nr += bcount[b];
+                    }
+                if (!nl || !nr) continue;
+                const double cost = l.area() * (double)nl + r.area() * (double)nr;
+                if (cost < best) {
+                    best = cost;
+                    best_split = sidx;
+                }
+            }
+            if (best_split < 0) {
+                mid = lo + n / 2;
+                std::nth_element(prims.begin() + lo, prims.begin() + mid, prims.begin() + hi,
+                                 [&](const Prim& a, const Prim& b) { return a.centroid[axis] < b.centroid[axis]; });
+            } else {
+                // stable_partition keeps the build deterministic
+                auto it = std::stable_partition(prims.begin() + lo, prims.begin() + hi,
+                                                [&](const Prim& p) { return bin_of(p) < best_split; });
+                mid = (size_t)(it - prims.begin());
+            }
         }
-        nodes[me].leaf = kNoLeaf;
-        build(lo, mid);
-        build(mid, hi);
+        TreeNode node;
+        node.box = box;
+        node.axis = axis;
+        const int me = (int)tree.size();
+        tree.push_back(node);
+        const int l = build(lo, mid);
+        const int r = build(mid, hi);
+        tree[me].left = l;
+        tree[me].right = r;
+        return me;
+    }
+
+    // One threaded pre-order layout: a ray whose direction is negative along a node's split axis
+    // (bit `axis` of `octant` set) comes from the high side and takes the right child first.
+    void emit(int t, uint32_t octant, std::vector<Node>& nodes) const {
+        const TreeNode& tn = tree[t];
+        const size_t me = nodes.size();
+        nodes.push_back(Node{});
+        for (int k = 0; k < 3; ++k) {
+            nodes[me].bmin[k] = down(tn.box.mn[k]);
+            nodes[me].bmax[k] = up(tn.box.mx[k]);
+        }
+        if (tn.left < 0) {
+            nodes[me].leaf = (tn.first_tri << 3) | tn.n_tris;
+        } else {
+            nodes[me].leaf = kNoLeaf;
+            const bool flip = (octant >> tn.axis) & 1u;
+            emit(flip ? tn.right : tn.left, octant, nodes);
+            emit(flip ? tn.left : tn.right, octant, nodes);
+        }
         nodes[me].skip = (uint32_t)nodes.size();
     }
 };
 
-// Build a BVH over shapes [first, first + count) (all triangles).  Appends to nodes/tris and
-// returns the root index, or kNoLeaf if the run cannot be bounded.
+// Build a BVH over shapes [first, first + count) (all triangles).  Appends the kLayouts threaded
+// layouts (equal size, one after the other: layout q starts at root + q * (nodes[root].skip - root))
+// to `nodes` and the leaf triangles to `tris`; returns the root of layout 0, or kNoLeaf if the run
+// cannot be bounded.
 inline uint32_t build_run(const rtx_shape* shapes, uint32_t first, uint32_t count, std::vector<Node>& nodes,
                           std::vector<Tri>& tris) {
-    Builder b{nodes, tris, shapes, {}};
+    Builder b{tris, shapes, {}, {}};
     b.prims.reserve(count);
     for (uint32_t i = 0; i < count; ++i) {
         const rtx_shape& s = shapes[first + i];
@@ -269,18 +303,21 @@ inline uint32_t build_run(const rtx_shape* shapes, uint32_t first, uint32_t coun
         b.prims.push_back(p);
     }
     const uint32_t root = (uint32_t)nodes.size();
-    if (b.prims.empty()) {  // nothing can be hit: an empty leaf
-        Node n{};
-        n.leaf = (uint32_t)(tris.size() << 3);
-        n.skip = root + 1;
-        for (int k = 0; k < 3; ++k) {
-            n.bmin[k] = INFINITY;
-            n.bmax[k] = -INFINITY;
+    if (b.prims.empty()) {  // nothing can be hit: an empty leaf (in every layout)
+        for (uint32_t q = 0; q < kLayouts; ++q) {
+            Node n{};
+            n.leaf = (uint32_t)(tris.size() << 3);
+            n.skip = (uint32_t)nodes.size() + 1;
+            for (int k = 0; k < 3; ++k) {
+                n.bmin[k] = INFINITY;
+                n.bmax[k] = -INFINITY;
+            }
+            nodes.push_back(n);
         }
-        nodes.push_back(n);
         return root;
     }
-    b.build(0, b.prims.size());
+    const int top = b.build(0, b.prims.size());
+    for (uint32_t q = 0; q < kLayouts; ++q) b.emit(top, q, nodes);
     return root;
 }
 

@@ -560,8 +560,14 @@ template <bool C, class V>
 RTX_HD void traverse_bvh(V& v, const Params& p, uint32_t root, V4 o, V4 d) {
     const float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
     const rtx_bvh::Node* nodes = p.bvh_nodes;
-    uint32_t n = root;
-    const uint32_t end = nodes[root].skip;
+    // The tree comes in rtx_bvh::kLayouts threaded layouts of equal size, one per octant of the
+    // ray direction, each visiting the nearer child of every split first (the predecessor walk
+    // looks backwards and takes the opposite octant).
+    const uint32_t stride = nodes[root].skip - root;
+    uint32_t octant = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
+    if (V::kBvhPred) octant ^= 7u;
+    uint32_t n = root + octant * stride;
+    const uint32_t end = n + stride;
     uint32_t tri = 0, tri_end = 0;  // pending leaf: triangles [tri, tri_end)
     for (;;) {
         while (tri == tri_end && n < end && !v.done()) {
@@ -1972,33 +1978,40 @@ int rtx_bvh_selftest(const rtx_scene_desc* desc, const float* origins, const flo
     for (const rtx_node& g : nodes) {
         if (!g.reserved[0]) continue;
         const uint32_t root = g.reserved[0] - 1u, first_tri = g.first_shape + g.reserved[1], last_tri = g.first_shape + g.n_shapes;
-        const uint32_t end = bn[root].skip;
-        if (end <= root || end > bn.size()) return fail(RTX_E_INVALID, "bvh %u: bad extent", root);
-        // structure: skips move forward and stay inside the parent, every hittable triangle of the run sits in exactly one leaf
-        std::vector<uint32_t> seen(last_tri - first_tri, 0u);
-        for (uint32_t k = root; k < end; ++k) {
-            const rtx_bvh::Node& nd = bn[k];
-            if (nd.skip <= k || nd.skip > end) return fail(RTX_E_INVALID, "bvh node %u: skip %u leaves [%u, %u)", k, nd.skip, root, end);
-            if (nd.leaf == rtx_bvh::kNoLeaf) {
-                if (nd.skip == k + 1u) return fail(RTX_E_INVALID, "bvh node %u: interior node without children", k);
-                continue;
+        const uint32_t stride = bn[root].skip - root;
+        if (bn[root].skip <= root || (size_t)root + (size_t)rtx_bvh::kLayouts * stride > bn.size())
+            return fail(RTX_E_INVALID, "bvh %u: bad extent", root);
+        // structure of every layout: skips move forward and stay inside the parent, every hittable
+        // triangle of the run sits in exactly one leaf
+        for (uint32_t q = 0; q < rtx_bvh::kLayouts; ++q) {
+            const uint32_t lo = root + q * stride, end = lo + stride;
+            if (bn[lo].skip != end) return fail(RTX_E_INVALID, "bvh %u layout %u: root skip %u != %u", root, q, bn[lo].skip, end);
+            std::vector<uint32_t> seen(last_tri - first_tri, 0u);
+            for (uint32_t k = lo; k < end; ++k) {
+                const rtx_bvh::Node& nd = bn[k];
+                if (nd.skip <= k || nd.skip > end) return fail(RTX_E_INVALID, "bvh node %u: skip %u leaves [%u, %u)", k, nd.skip, lo, end);
+                if (nd.leaf == rtx_bvh::kNoLeaf) {
+                    if (nd.skip == k + 1u) return fail(RTX_E_INVALID, "bvh node %u: interior node without children", k);
+                    continue;
+                }
+                if (nd.skip != k + 1u) return fail(RTX_E_INVALID, "bvh node %u: a leaf with a subtree", k);
+                const uint32_t t0 = nd.leaf >> 3, cnt = nd.leaf & 7u;
+                if ((size_t)t0 + cnt > bt.size()) return fail(RTX_E_INVALID, "bvh node %u: leaf out of range", k);
+                for (uint32_t t = t0; t < t0 + cnt; ++t) {
+                    const rtx_bvh::Tri& tr = bt[t];
+                    if (tr.shape < first_tri || tr.shape >= last_tri) return fail(RTX_E_INVALID, "bvh leaf %u: foreign triangle %u", k, tr.shape);
+                    seen[tr.shape - first_tri]++;
+                    if (std::memcmp(tr.p0, shapes[tr.shape].p0, 12) || std::memcmp(tr.e0, shapes[tr.shape].e0, 12) ||
+                        std::memcmp(tr.e1, shapes[tr.shape].e1, 12) || tr.flags != shapes[tr.shape].flags)
+                        return fail(RTX_E_INVALID, "bvh leaf %u: triangle %u differs from its shape", k, tr.shape);
+                }
             }
-            if (nd.skip != k + 1u) return fail(RTX_E_INVALID, "bvh node %u: a leaf with a subtree", k);
-            const uint32_t t0 = nd.leaf >> 3, cnt = nd.leaf & 7u;
-            if ((size_t)t0 + cnt > bt.size()) return fail(RTX_E_INVALID, "bvh node %u: leaf out of range", k);
-            for (uint32_t t = t0; t < t0 + cnt; ++t) {
-                const rtx_bvh::Tri& tr = bt[t];
-                if (tr.shape < first_tri || tr.shape >= last_tri) return fail(RTX_E_INVALID, "bvh leaf %u: foreign triangle %u", k, tr.shape);
-                seen[tr.shape - first_tri]++;
-                if (std::memcmp(tr.p0, shapes[tr.shape].p0, 12) || std::memcmp(tr.e0, shapes[tr.shape].e0, 12) ||
-                    std::memcmp(tr.e1, shapes[tr.shape].e1, 12) || tr.flags != shapes[tr.shape].flags)
-                    return fail(RTX_E_INVALID, "bvh leaf %u: triangle %u differs from its shape", k, tr.shape);
+            for (uint32_t t = first_tri; t < last_tri; ++t) {
+                const rtx_shape& sh = shapes[t];
+                const bool degenerate = sh.e0[0] == 0.0f && sh.e0[1] == 0.0f && sh.e0[2] == 0.0f && sh.e0[3] == 0.0f;
+                if (seen[t - first_tri] != (degenerate ? 0u : 1u))
+                    return fail(RTX_E_INVALID, "layout %u: triangle %u sits in %u leaves", q, t, seen[t - first_tri]);
             }
-        }
-        for (uint32_t t = first_tri; t < last_tri; ++t) {
-            const rtx_shape& sh = shapes[t];
-            const bool degenerate = sh.e0[0] == 0.0f && sh.e0[1] == 0.0f && sh.e0[2] == 0.0f && sh.e0[3] == 0.0f;
-            if (seen[t - first_tri] != (degenerate ? 0u : 1u)) return fail(RTX_E_INVALID, "triangle %u sits in %u leaves", t, seen[t - first_tri]);
         }
         // rays: the traversal (closest hit, then the predecessor walk) against brute force
         Params p;
