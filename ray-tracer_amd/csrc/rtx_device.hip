@@ -1586,7 +1586,7 @@ int run_levels(rtx_scene* s, WorkSet& w, Params& p, uint32_t pixels, uint32_t le
         if (!prof) return;
         if (s->prof_used == s->prof_events.size()) {
             hipEvent_t e;
-            if (hipEventCreate(&e) != hipSuccess) return;
+            if (hipEventCreateWithFlags(&e, hipEventReleaseToDevice) != hipSuccess) return;  // device-scope release: no system-wide flush around the timed launch
             s->prof_events.push_back(e);
         }
         (void)hipEventRecord(s->prof_events[s->prof_used++], st);
