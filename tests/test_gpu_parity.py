@@ -512,3 +512,16 @@ def test_scene_lifecycle_returns_device_memory():
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < 64 << 20, "device memory shrank by %d MiB over 20 scene lifecycles" % ((free0 - free1) >> 20)
+
+
+def test_by_value_rt_color_at_and_camera_init():
+    # colorAt (src/world.zig:81-83) through the by-value drop-in: world struct in, colours out
+    s = rta.Sample("cylinder_world", 64, 32)
+    cam = rta.camera(64, 32, float(np.float32(np.pi / 3.0)), (0, 1.5, -5, 1), (0, 1, 0, 1), (0, 1, 0, 0))  # rt_camera_init
+    rays = (st.Ray * 48)()
+    for k in range(48):
+        rta.lib().rt_ray_for_pixel(C.byref(cam), (k * 5) % 64, (k * 3) % 32, C.byref(rays[k]))
+    out = np.zeros((48, 3), np.float32)
+    assert rta.lib().rt_color_at(C.byref(s.world), rays, 48, rta.fptr(out)) == 0
+    ref = np.stack([o.color_at(s.world, list(rays[k].origin), list(rays[k].direction)) for k in range(48)])
+    compare(out[None], ref[None], "rt_color_at")
