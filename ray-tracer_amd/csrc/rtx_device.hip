@@ -159,6 +159,7 @@ struct Params {
     uint32_t level_shift;  // 1: some material spawns two children per hit (levels may double); 0: at most one
 
     Counters* counters;
+    Counters* counters_next;  // the set the NEXT batch will use: level 0 of this batch clears it
     float* canvas;        // root results land here: 3 floats per root index
     uint32_t root_count;  // level-0 work items when rays come from the queue (rtx_color_at)
 };
@@ -932,6 +933,15 @@ __attribute__((amdgpu_waves_per_eu((BVH || !C) ? RTX_WAVES_PER_EU : RTX_WAVES_PE
         tab.patterns = reinterpret_cast<const rtx_pattern*>(lds_raw + n_sh + n_ma);
     }
     const bool root = level == 0;
+    // Two counter sets alternate between batches: while this batch allocates from one, its first
+    // launch clears the other for the batch after it (everything that used that set finished
+    // before this kernel started), so frames that do not ask for statistics need neither a fill
+    // nor k_accumulate between batches.
+    if (root && blockIdx.x == 0 && threadIdx.x < kShards) {
+        uint4* line = reinterpret_cast<uint4*>(&p.counters_next->shard[threadIdx.x]);
+#pragma unroll
+        for (int k = 0; k < (int)(sizeof(ShardCounters) / sizeof(uint4)); ++k) line[k] = make_uint4(0u, 0u, 0u, 0u);
+    }
     const uint32_t remaining = p.depth - level;  // `remaining` of colorAtInternal (src/world.zig:85)
     const uint32_t qi = level & 1u, qo = qi ^ 1u;
     const uint32_t lane = threadIdx.x & 63u;
@@ -1254,7 +1264,8 @@ struct WorkSet {
     float4* node_b = nullptr;
     float4* node_c = nullptr;
     uint2* node_d = nullptr;
-    Counters* d_counters = nullptr;
+    Counters* d_counters = nullptr;  // two sets, used alternately by successive batches (see k_trace_shade)
+    uint32_t counter_set = 0;        // the set the next batch uses
     Totals* d_totals = nullptr;
     bool counters_dirty = true;    // d_counters are not known to be zero (see run_levels)
     hipStream_t stream = nullptr;  // lane stream (lane 0 of a single-lane frame runs on the caller's)
@@ -1360,7 +1371,8 @@ void bind_work(Params& p, const WorkSet& w) {
     p.node_b = w.node_b;
     p.node_c = w.node_c;
     p.node_d = w.node_d;
-    p.counters = w.d_counters;
+    p.counters = w.d_counters + w.counter_set;
+    p.counters_next = w.d_counters + (w.counter_set ^ 1u);
 }
 
 int ensure_canvas(rtx_scene* s, size_t floats) {
@@ -1546,10 +1558,11 @@ int collect_profile(rtx_scene* s, rtx_stats* out) {
 // queue 0 (rtx_color_at).
 template <bool GEN>
 int run_levels(rtx_scene* s, WorkSet& w, Params& p, uint32_t pixels, uint32_t level0_items, hipStream_t st, bool prof,
-               bool first) {
-    // k_accumulate leaves the shard counters at zero for the next batch; they are cleared here
-    // only when that did not happen (fresh buffers, or an earlier batch that failed half way).
-    if (w.counters_dirty) HIP_TRY(hipMemsetAsync(w.d_counters, 0, sizeof(Counters), st));
+               bool first, bool want_totals) {
+    // Each batch finds its counter set cleared by the batch before it (k_trace_shade, level 0);
+    // both sets are cleared here only when that cannot be relied on (fresh buffers, or an
+    // earlier batch that failed half way).
+    if (w.counters_dirty) HIP_TRY(hipMemsetAsync(w.d_counters, 0, 2 * sizeof(Counters), st));
     w.counters_dirty = true;
     bind_work(p, w);
     p.shard_cap0 = w.shard_cap0;
@@ -1609,9 +1622,12 @@ int run_levels(rtx_scene* s, WorkSet& w, Params& p, uint32_t pixels, uint32_t le
         hipLaunchKernelGGL(k_combine, dim3(blocks), dim3(256), 0, st, p, (uint32_t)level);
         mark(-1);
     }
-    hipLaunchKernelGGL(k_accumulate, dim3(1), dim3(kShards), 0, st, w.d_counters, w.d_totals, level0_items ? pixels : 0u, last_level,
-                       first ? 1u : 0u);
+    // Frame totals (ray counts by level, hit kinds) only when the caller reads them back.
+    if (want_totals)
+        hipLaunchKernelGGL(k_accumulate, dim3(1), dim3(kShards), 0, st, p.counters, w.d_totals, level0_items ? pixels : 0u, last_level,
+                           first ? 1u : 0u);
     HIP_TRY(hipGetLastError());
+    w.counter_set ^= 1u;
     w.counters_dirty = false;
     return RTX_OK;
 }
@@ -1710,7 +1726,7 @@ int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_opts* opts, float
         p.n_rows = n_rows;
         const uint32_t items = tiles_x * ((n_rows + 7u) / 8u) * 64u;
         const int l = (int)(batch % (uint32_t)lanes);
-        rc = run_levels<true>(s, s->ws[l], p, cap, items, lane_stream[l], profile, batch < (uint32_t)lanes);
+        rc = run_levels<true>(s, s->ws[l], p, cap, items, lane_stream[l], profile, batch < (uint32_t)lanes, stats != nullptr);
         if (rc) return rc;
     }
     const int lanes_used = batch < (uint32_t)lanes ? (int)batch : lanes;
@@ -1866,7 +1882,7 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out) {
     HIP_TRY_S(upload((void**)&s->d_patterns, desc->patterns, sizeof(rtx_pattern) * desc->n_patterns));
     HIP_TRY_S(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
     for (WorkSet& w : s->ws) {
-        HIP_TRY_S(hipMalloc(&w.d_counters, sizeof(Counters)));
+        HIP_TRY_S(hipMalloc(&w.d_counters, 2 * sizeof(Counters)));
         HIP_TRY_S(hipMalloc(&w.d_totals, sizeof(Totals)));
         HIP_TRY_S(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
         HIP_TRY_S(hipEventCreateWithFlags(&w.done, hipEventDisableTiming));
@@ -2100,7 +2116,7 @@ int rtx_color_at(rtx_scene* s, const float* origins, const float* directions, ui
     p.canon = canon ? 1u : 0u;
     p.canvas = s->d_canvas;
     p.root_count = n;
-    rc = run_levels<false>(s, w, p, n, n, st, false, true);
+    rc = run_levels<false>(s, w, p, n, n, st, false, true, false);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(rgb_out, s->d_canvas, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));

@@ -207,6 +207,33 @@ def test_device_canvas_and_u8_quantisation():
     scene.close()
 
 
+def test_frames_without_statistics_leave_the_counters_right_for_the_next_frame():
+    """Frames that do not ask for statistics skip the totals kernel and rely on the alternating
+    counter sets; a frame with statistics after any number of them must still count right, for
+    multi-batch frames and for a different scene size in between."""
+    import torch
+
+    s = rta.Sample("glass_spheres", 200, 120)
+    small = rta.Sample("glass_spheres", 64, 40)
+    scene = rta.Scene(s.world)
+    host, ref_stats = scene.render(s.camera)
+    rgb = torch.zeros((120, 200, 3), dtype=torch.float32, device="cuda")
+    rgb_small = torch.zeros((40, 64, 3), dtype=torch.float32, device="cuda")
+    for quiet in (1, 2, 3):
+        for _ in range(quiet):
+            rgb.zero_()
+            assert scene.render_device(s.camera, rgb.data_ptr(), None) is None
+            torch.cuda.synchronize()
+            assert rgb.cpu().numpy().tobytes() == host.tobytes()
+        scene.render_device(small.camera, rgb_small.data_ptr(), None, batch_pixels=64 * 8)
+        scene.color_at([[0.0, 0.0, -5.0, 1.0]] * quiet, [[0.0, 0.0, 1.0, 0.0]] * quiet)
+        st =scene.render_device(s.camera, rgb.data_ptr(), None, want_stats=True, batch_pixels=200 * 8 * (quiet + 1))
+        torch.cuda.synchronize()
+        assert st.rays_total == ref_stats.rays_total and list(st.level_rays) == list(ref_stats.level_rays)
+        assert rgb.cpu().numpy().tobytes() == host.tobytes()
+    scene.close()
+
+
 def test_invalid_arguments_are_rejected():
     s = rta.Sample("cone", 32, 32)
     flat = rta.FlatScene(s.world)
