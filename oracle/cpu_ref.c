@@ -42,6 +42,46 @@
 
 #define EXPORT __attribute__((visibility("default")))
 
+/* The reference is f32 end to end (src/tuple.zig:6,10); `real` is float in the
+ * oracle proper.  -DORACLE_F64 builds a second library (liboracle_f64.so) whose
+ * ray/shading arithmetic runs in double on the same f32 scene records — used only
+ * by the sensitivity test that reproduces SURVEY.md §8c's "f64 arithmetic" row
+ * (how far an f64 renderer would sit from the f32 reference); never the parity
+ * oracle. */
+#ifdef ORACLE_F64
+typedef double real;
+#define R_SQRT sqrt
+#define R_FABS fabs
+#define R_FLOOR floor
+#define R_FMA fma
+#define R_FMAX fmax
+#define R_FMIN fmin
+#define R_FMOD fmod
+#define R_FREXP frexp
+#define R_LDEXP ldexp
+#define R_MODF modf
+#define R_COPYSIGN copysign
+#define R_EXP exp
+#define R_LOG log
+#define R_POW pow
+#else
+typedef float real;
+#define R_SQRT sqrtf
+#define R_FABS fabsf
+#define R_FLOOR floorf
+#define R_FMA fmaf
+#define R_FMAX fmaxf
+#define R_FMIN fminf
+#define R_FMOD fmodf
+#define R_FREXP frexpf
+#define R_LDEXP ldexpf
+#define R_MODF modff
+#define R_COPYSIGN copysignf
+#define R_EXP expf
+#define R_LOG logf
+#define R_POW powf
+#endif
+
 /* ------------------------------------------------------------------ options */
 
 /* 0 = glibc libm, 1 = Zig 0.9 std.math restatement (default). */
@@ -55,23 +95,23 @@ EXPORT void oracle_set_containers(int book) { g_containers_book = book; }
 
 /* ------------------------------------------------------------- tuple.zig */
 
-typedef struct { float v[4]; } tuple;
-typedef struct { float c[3]; } color;
+typedef struct { real v[4]; } tuple;
+typedef struct { real c[3]; } color;
 
-static const float epsilon = 0.00001f; /* src/tuple.zig:10 */
+static const real epsilon = 0.00001f; /* src/tuple.zig:10 */
 
-static tuple tup4(float x, float y, float z, float w) { tuple t = {{x, y, z, w}}; return t; }
-static tuple point(float x, float y, float z) { return tup4(x, y, z, 1.0f); }   /* tuple.zig:16 */
-static tuple vector(float x, float y, float z) { return tup4(x, y, z, 0.0f); }  /* tuple.zig:20 */
+static tuple tup4(real x, real y, real z, real w) { tuple t = {{x, y, z, w}}; return t; }
+static tuple point(real x, real y, real z) { return tup4(x, y, z, 1.0f); }   /* tuple.zig:16 */
+static tuple vector(real x, real y, real z) { return tup4(x, y, z, 0.0f); }  /* tuple.zig:20 */
 
 static tuple tadd(tuple a, tuple b) { return tup4(a.v[0] + b.v[0], a.v[1] + b.v[1], a.v[2] + b.v[2], a.v[3] + b.v[3]); }
 static tuple tsub(tuple a, tuple b) { return tup4(a.v[0] - b.v[0], a.v[1] - b.v[1], a.v[2] - b.v[2], a.v[3] - b.v[3]); }
-static tuple tmuls(tuple a, float s) { return tup4(a.v[0] * s, a.v[1] * s, a.v[2] * s, a.v[3] * s); }
-static tuple tdivs(tuple a, float s) { return tup4(a.v[0] / s, a.v[1] / s, a.v[2] / s, a.v[3] / s); }
+static tuple tmuls(tuple a, real s) { return tup4(a.v[0] * s, a.v[1] * s, a.v[2] * s, a.v[3] * s); }
+static tuple tdivs(tuple a, real s) { return tup4(a.v[0] / s, a.v[1] / s, a.v[2] / s, a.v[3] / s); }
 static tuple tneg(tuple a) { return tup4(-a.v[0], -a.v[1], -a.v[2], -a.v[3]); }
 
 /* tuple.zig:38-40 — all four lanes, left to right. */
-static float dot(tuple u, tuple v) {
+static real dot(tuple u, tuple v) {
     return u.v[0] * v.v[0] + u.v[1] * v.v[1] + u.v[2] * v.v[2] + u.v[3] * v.v[3];
 }
 
@@ -84,7 +124,7 @@ static tuple cross(tuple u, tuple v) {
                 0.0f);
 }
 
-static float magnitude(tuple v) { return sqrtf(dot(v, v)); }        /* tuple.zig:50-52 */
+static real magnitude(tuple v) { return R_SQRT(dot(v, v)); }        /* tuple.zig:50-52 */
 static tuple normalize(tuple v) { return tdivs(v, magnitude(v)); }  /* tuple.zig:54-56 */
 
 /* tuple.zig:58-77 */
@@ -96,7 +136,7 @@ static tuple reflect(tuple incident, tuple normal) {
 /* tuple.zig:32-36 */
 static int tup_equal(tuple a, tuple b) {
     for (int i = 0; i < 4; ++i)
-        if (!(fabsf(a.v[i] - b.v[i]) <= epsilon)) return 0;
+        if (!(R_FABS(a.v[i] - b.v[i]) <= epsilon)) return 0;
     return 1;
 }
 
@@ -249,19 +289,19 @@ static mat4 inverse(mat4 a) {
 /* std.math.pow(f32, x, y), Zig 0.9 lib/std/math/pow.zig — a port of Go's
  * math.Pow (golang.org/src/math/pow.go): integer part of y by repeated squaring
  * on the frexp'd significand, fractional part via exp(yf*ln(x)). */
-static int is_odd_integer(float y) {
-    float ip;
-    float fp = modff(y, &ip);
+static int is_odd_integer(real y) {
+    real ip;
+    real fp = R_MODF(y, &ip);
     return fp == 0 && (((int64_t)ip) & 1) == 1;
 }
 
-static float zig_pow(float x, float y) {
+static real zig_pow(real x, real y) {
     if (y == 0 || x == 1) return 1;
     if (isnan(x) || isnan(y)) return NAN;
     if (y == 1) return x;
     if (x == 0) {
         if (y < 0) {
-            if (is_odd_integer(y)) return copysignf(INFINITY, x);
+            if (is_odd_integer(y)) return R_COPYSIGN(INFINITY, x);
             return INFINITY;
         } else {
             if (is_odd_integer(y)) return x;
@@ -270,7 +310,7 @@ static float zig_pow(float x, float y) {
     }
     if (isinf(y)) {
         if (x == -1) return 1.0f;
-        if ((fabsf(x) < 1) == (y > 0)) return 0;
+        if ((R_FABS(x) < 1) == (y > 0)) return 0;
         return INFINITY;
     }
     if (isinf(x)) {
@@ -278,22 +318,22 @@ static float zig_pow(float x, float y) {
         if (y < 0) return 0;
         if (y > 0) return INFINITY;
     }
-    if (y == 0.5f) return sqrtf(x);
-    if (y == -0.5f) return 1 / sqrtf(x);
+    if (y == 0.5f) return R_SQRT(x);
+    if (y == -0.5f) return 1 / R_SQRT(x);
 
-    float yi;
-    float yf = modff(fabsf(y), &yi);
+    real yi;
+    real yf = R_MODF(R_FABS(y), &yi);
     if (yf != 0 && x < 0) return NAN;
-    if (yi >= 2147483648.0f) return expf(y * logf(x));
+    if (yi >= 2147483648.0f) return R_EXP(y * R_LOG(x));
 
-    float a1 = 1.0f;
+    real a1 = 1.0f;
     int32_t ae = 0;
     if (yf != 0) {
         if (yf > 0.5f) { yf -= 1; yi += 1; }
-        a1 = expf(yf * logf(x));
+        a1 = R_EXP(yf * R_LOG(x));
     }
     int xe;
-    float x1 = frexpf(x, &xe);
+    real x1 = R_FREXP(x, &xe);
     int32_t i = (int32_t)yi;
     while (i != 0) {
         const int overflow_shift = 8 + 1;
@@ -308,7 +348,7 @@ static float zig_pow(float x, float y) {
         i >>= 1;
     }
     if (y < 0) { a1 = 1 / a1; ae = -ae; }
-    return ldexpf(a1, ae);
+    return R_LDEXP(a1, ae);
 }
 
 /* Zig 0.9 lib/std/math/{sin,cos,tan}.zig — ports of Go's math.Sin/Cos/Tan
@@ -387,7 +427,7 @@ static float zig_tan(float x_) {
 static float m_sin(float x) { return g_libm ? zig_sin(x) : sinf(x); }
 static float m_cos(float x) { return g_libm ? zig_cos(x) : cosf(x); }
 static float m_tan(float x) { return g_libm ? zig_tan(x) : tanf(x); }
-static float m_pow(float x, float y) { return g_libm ? zig_pow(x, y) : powf(x, y); }
+static real m_pow(real x, real y) { return g_libm ? zig_pow(x, y) : R_POW(x, y); }
 
 /* matrix.zig:170-222 */
 static mat4 translation(float x, float y, float z) {
@@ -419,7 +459,7 @@ static mat4 shearing(float xy, float xz, float yx, float yz, float zx, float zy)
 
 typedef struct { tuple origin, direction; } ray;
 
-static tuple position(ray r, float t) { return tadd(r.origin, tmuls(r.direction, t)); } /* ray.zig:9-11 */
+static tuple position(ray r, real t) { return tadd(r.origin, tmuls(r.direction, t)); } /* ray.zig:9-11 */
 
 static ray ray_transform(ray r, mat4 m) { /* ray.zig:13-18 */
     ray o = {mul_tuple(m, r.origin), mul_tuple(m, r.direction)};
@@ -444,7 +484,7 @@ typedef struct {
 } shape;
 
 /* intersection.zig:9-12 — the shape travels by value. */
-typedef struct { float t; shape s; } intersection;
+typedef struct { real t; shape s; } intersection;
 
 typedef struct { intersection* items; size_t len, cap; } xs_list;
 
@@ -456,7 +496,7 @@ static void xs_append(xs_list* xs, const intersection* x) {
     xs->items[xs->len++] = *x;
 }
 
-static void append_hit(xs_list* xs, float t, int kind, const void* self, size_t size) {
+static void append_hit(xs_list* xs, real t, int kind, const void* self, size_t size) {
     intersection x;
     memset(&x, 0, sizeof x);
     x.t = t;
@@ -543,12 +583,14 @@ static int intersection_eql(const intersection* a, const intersection* b) {
 }
 
 static tuple tup_from(const float* p) { return tup4(p[0], p[1], p[2], p[3]); }
+/* Records and exported results are f32 whatever `real` is. */
+static void tup_store(float* dst, tuple t) { for (int i = 0; i < 4; ++i) dst[i] = (float)t.v[i]; }
 
 /* std.math.approxEqAbs(f32, x, y, tol) */
-static int approx_eq_abs(float x, float y, float tol) {
+static int approx_eq_abs(real x, real y, real tol) {
     if (x == y) return 1;
     if (isnan(x) || isnan(y)) return 0;
-    return fabsf(x - y) <= tol;
+    return R_FABS(x - y) <= tol;
 }
 
 /* ------------------------------------------------------------ sphere.zig */
@@ -556,13 +598,13 @@ static int approx_eq_abs(float x, float y, float tol) {
 static void sphere_intersect(const rt_sphere* self, ray r, xs_list* xs) { /* sphere.zig:11-54 */
     ray rp = ray_transform(r, inverse(self->common_attrs.transform));
     tuple sphere_to_ray = tsub(rp.origin, point(0, 0, 0));
-    float a = dot(rp.direction, rp.direction);
-    float b = 2 * dot(rp.direction, sphere_to_ray);
-    float c = dot(sphere_to_ray, sphere_to_ray) - 1;
-    float discriminant = b * b - 4 * a * c;
+    real a = dot(rp.direction, rp.direction);
+    real b = 2 * dot(rp.direction, sphere_to_ray);
+    real c = dot(sphere_to_ray, sphere_to_ray) - 1;
+    real discriminant = b * b - 4 * a * c;
     if (discriminant >= 0) {
-        float t0 = (-b - sqrtf(discriminant)) / (2 * a);
-        float t1 = (-b + sqrtf(discriminant)) / (2 * a);
+        real t0 = (-b - R_SQRT(discriminant)) / (2 * a);
+        real t1 = (-b + R_SQRT(discriminant)) / (2 * a);
         append_hit(xs, t0, K_SPHERE, self, sizeof *self);
         append_hit(xs, t1, K_SPHERE, self, sizeof *self);
     }
@@ -581,8 +623,8 @@ static tuple sphere_normal_at(const rt_sphere* s, tuple world_point) { /* sphere
 
 static void plane_intersect(const rt_plane* self, ray r, xs_list* xs) { /* plane.zig:13-28 */
     ray rp = ray_transform(r, inverse(self->common_attrs.transform));
-    if (fabsf(rp.direction.v[1]) < epsilon) return;
-    float t = -rp.origin.v[1] / rp.direction.v[1];
+    if (R_FABS(rp.direction.v[1]) < epsilon) return;
+    real t = -rp.origin.v[1] / rp.direction.v[1];
     append_hit(xs, t, K_PLANE, self, sizeof *self);
 }
 
@@ -595,13 +637,13 @@ static tuple plane_normal_at(const rt_plane* self, tuple world_point) { /* plane
 
 /* -------------------------------------------------------------- cube.zig */
 
-typedef struct { float tmin, tmax; } tminmax;
+typedef struct { real tmin, tmax; } tminmax;
 
-static tminmax cube_check_axis(float origin, float direction) { /* cube.zig:52-67 */
-    float tmin_numerator = -1 - origin;
-    float tmax_numerator = 1 - origin;
-    float tmin, tmax;
-    if (fabsf(direction) >= epsilon) {
+static tminmax cube_check_axis(real origin, real direction) { /* cube.zig:52-67 */
+    real tmin_numerator = -1 - origin;
+    real tmax_numerator = 1 - origin;
+    real tmin, tmax;
+    if (R_FABS(direction) >= epsilon) {
         tmin = tmin_numerator / direction;
         tmax = tmax_numerator / direction;
     } else {
@@ -614,14 +656,14 @@ static tminmax cube_check_axis(float origin, float direction) { /* cube.zig:52-6
 }
 
 /* @maximum/@minimum lower to llvm.maxnum/minnum: a NaN operand is ignored,
- * which is fmaxf/fminf. */
+ * which is R_FMAX/R_FMIN. */
 static void cube_intersect(const rt_cube* self, ray r, xs_list* xs) { /* cube.zig:11-26 */
     ray rp = ray_transform(r, inverse(self->common_attrs.transform));
     tminmax x = cube_check_axis(rp.origin.v[0], rp.direction.v[0]);
     tminmax y = cube_check_axis(rp.origin.v[1], rp.direction.v[1]);
     tminmax z = cube_check_axis(rp.origin.v[2], rp.direction.v[2]);
-    float tmin = fmaxf(x.tmin, fmaxf(y.tmin, z.tmin));
-    float tmax = fminf(x.tmax, fminf(y.tmax, z.tmax));
+    real tmin = R_FMAX(x.tmin, R_FMAX(y.tmin, z.tmin));
+    real tmax = R_FMIN(x.tmax, R_FMIN(y.tmax, z.tmax));
     if (tmin > tmax) return;
     append_hit(xs, tmin, K_CUBE, self, sizeof *self);
     append_hit(xs, tmax, K_CUBE, self, sizeof *self);
@@ -630,10 +672,10 @@ static void cube_intersect(const rt_cube* self, ray r, xs_list* xs) { /* cube.zi
 static tuple cube_normal_at(const rt_cube* self, tuple world_point) { /* cube.zig:28-44 */
     mat4 inv = inverse(self->common_attrs.transform);
     tuple object_point = mul_tuple(inv, world_point);
-    float x = fabsf(object_point.v[0]);
-    float y = fabsf(object_point.v[1]);
-    float z = fabsf(object_point.v[2]);
-    float maxc = fmaxf(x, fmaxf(y, z));
+    real x = R_FABS(object_point.v[0]);
+    real y = R_FABS(object_point.v[1]);
+    real z = R_FABS(object_point.v[2]);
+    real maxc = R_FMAX(x, R_FMAX(y, z));
     tuple object_normal;
     if (maxc == x) object_normal = vector(object_point.v[0], 0, 0);
     else if (maxc == y) object_normal = vector(0, object_point.v[1], 0);
@@ -644,41 +686,41 @@ static tuple cube_normal_at(const rt_cube* self, tuple world_point) { /* cube.zi
 
 /* ---------------------------------------------------------- cylinder.zig */
 
-static int cyl_check_cap(ray r, float t) { /* cylinder.zig:95-101 */
-    float x = fmaf(t, r.direction.v[0], r.origin.v[0]);
-    float z = fmaf(t, r.direction.v[2], r.origin.v[2]);
+static int cyl_check_cap(ray r, real t) { /* cylinder.zig:95-101 */
+    real x = R_FMA(t, r.direction.v[0], r.origin.v[0]);
+    real z = R_FMA(t, r.direction.v[2], r.origin.v[2]);
     return (x * x + z * z) <= 1;
 }
 
 static void cyl_intersect_caps(const rt_cylinder* self, ray rp, xs_list* xs) { /* cylinder.zig:53-71 */
     if (!self->closed || approx_eq_abs(rp.direction.v[1], 0, epsilon)) return;
-    float t_lower = (self->minimum - rp.origin.v[1]) / rp.direction.v[1];
+    real t_lower = (self->minimum - rp.origin.v[1]) / rp.direction.v[1];
     if (cyl_check_cap(rp, t_lower)) append_hit(xs, t_lower, K_CYLINDER, self, sizeof *self);
-    float t_upper = (self->maximum - rp.origin.v[1]) / rp.direction.v[1];
+    real t_upper = (self->maximum - rp.origin.v[1]) / rp.direction.v[1];
     if (cyl_check_cap(rp, t_upper)) append_hit(xs, t_upper, K_CYLINDER, self, sizeof *self);
 }
 
 static void cylinder_intersect(const rt_cylinder* self, ray r, xs_list* xs) { /* cylinder.zig:14-51 */
     ray rp = ray_transform(r, inverse(self->common_attrs.transform));
-    float a = rp.direction.v[0] * rp.direction.v[0] + rp.direction.v[2] * rp.direction.v[2];
+    real a = rp.direction.v[0] * rp.direction.v[0] + rp.direction.v[2] * rp.direction.v[2];
     if (approx_eq_abs(a, 0, epsilon)) {
         cyl_intersect_caps(self, rp, xs);
         return;
     }
-    float b = 2 * rp.origin.v[0] * rp.direction.v[0] + 2 * rp.origin.v[2] * rp.direction.v[2];
-    float c = rp.origin.v[0] * rp.origin.v[0] + rp.origin.v[2] * rp.origin.v[2] - 1;
-    float discriminant = b * b - 4 * a * c;
+    real b = 2 * rp.origin.v[0] * rp.direction.v[0] + 2 * rp.origin.v[2] * rp.direction.v[2];
+    real c = rp.origin.v[0] * rp.origin.v[0] + rp.origin.v[2] * rp.origin.v[2] - 1;
+    real discriminant = b * b - 4 * a * c;
     if (discriminant < 0) {
         cyl_intersect_caps(self, rp, xs);
         return;
     }
-    float t0 = (-b - sqrtf(discriminant)) / (2 * a);
-    float t1 = (-b + sqrtf(discriminant)) / (2 * a);
-    if (t0 > t1) { float tmp = t0; t0 = t1; t1 = tmp; }
+    real t0 = (-b - R_SQRT(discriminant)) / (2 * a);
+    real t1 = (-b + R_SQRT(discriminant)) / (2 * a);
+    if (t0 > t1) { real tmp = t0; t0 = t1; t1 = tmp; }
 
-    float y0 = fmaf(t0, rp.direction.v[1], rp.origin.v[1]);
+    real y0 = R_FMA(t0, rp.direction.v[1], rp.origin.v[1]);
     if (self->minimum < y0 && y0 < self->maximum) append_hit(xs, t0, K_CYLINDER, self, sizeof *self);
-    float y1 = fmaf(t1, rp.direction.v[1], rp.origin.v[1]);
+    real y1 = R_FMA(t1, rp.direction.v[1], rp.origin.v[1]);
     if (self->minimum < y1 && y1 < self->maximum) append_hit(xs, t1, K_CYLINDER, self, sizeof *self);
 
     cyl_intersect_caps(self, rp, xs);
@@ -688,7 +730,7 @@ static tuple cylinder_normal_at(const rt_cylinder* self, tuple world_point) { /*
     mat4 inv = inverse(self->common_attrs.transform);
     tuple object_normal;
     tuple object_point = mul_tuple(inv, world_point);
-    float distance = object_point.v[0] * object_point.v[0] + object_point.v[2] * object_point.v[2];
+    real distance = object_point.v[0] * object_point.v[0] + object_point.v[2] * object_point.v[2];
     if (distance < 1 && object_point.v[1] >= self->maximum - epsilon) {
         object_normal = vector(0, 1, 0);
     } else if (distance < 1 && object_point.v[1] <= self->minimum + epsilon) {
@@ -703,51 +745,51 @@ static tuple cylinder_normal_at(const rt_cylinder* self, tuple world_point) { /*
 
 /* -------------------------------------------------------------- cone.zig */
 
-static int cone_check_cap(ray r, float t, float y) { /* cone.zig:108-114 */
-    float x = fmaf(t, r.direction.v[0], r.origin.v[0]);
-    float z = fmaf(t, r.direction.v[2], r.origin.v[2]);
-    return (x * x + z * z) <= fabsf(y * y);
+static int cone_check_cap(ray r, real t, real y) { /* cone.zig:108-114 */
+    real x = R_FMA(t, r.direction.v[0], r.origin.v[0]);
+    real z = R_FMA(t, r.direction.v[2], r.origin.v[2]);
+    return (x * x + z * z) <= R_FABS(y * y);
 }
 
 static void cone_intersect_caps(const rt_cone* self, ray rp, xs_list* xs) { /* cone.zig:66-82 */
     if (!self->closed || approx_eq_abs(rp.direction.v[1], 0, epsilon)) return;
-    float t_lower = (self->minimum - rp.origin.v[1]) / rp.direction.v[1];
+    real t_lower = (self->minimum - rp.origin.v[1]) / rp.direction.v[1];
     if (cone_check_cap(rp, t_lower, self->minimum)) append_hit(xs, t_lower, K_CONE, self, sizeof *self);
-    float t_upper = (self->maximum - rp.origin.v[1]) / rp.direction.v[1];
+    real t_upper = (self->maximum - rp.origin.v[1]) / rp.direction.v[1];
     if (cone_check_cap(rp, t_upper, self->maximum)) append_hit(xs, t_upper, K_CONE, self, sizeof *self);
 }
 
 static void cone_intersect(const rt_cone* self, ray r, xs_list* xs) { /* cone.zig:14-64 */
     ray rp = ray_transform(r, inverse(self->common_attrs.transform));
-    float a = rp.direction.v[0] * rp.direction.v[0] - rp.direction.v[1] * rp.direction.v[1] +
+    real a = rp.direction.v[0] * rp.direction.v[0] - rp.direction.v[1] * rp.direction.v[1] +
               rp.direction.v[2] * rp.direction.v[2];
-    float b = 2 * rp.origin.v[0] * rp.direction.v[0] - 2 * rp.origin.v[1] * rp.direction.v[1] +
+    real b = 2 * rp.origin.v[0] * rp.direction.v[0] - 2 * rp.origin.v[1] * rp.direction.v[1] +
               2 * rp.origin.v[2] * rp.direction.v[2];
-    float c = rp.origin.v[0] * rp.origin.v[0] - rp.origin.v[1] * rp.origin.v[1] +
+    real c = rp.origin.v[0] * rp.origin.v[0] - rp.origin.v[1] * rp.origin.v[1] +
               rp.origin.v[2] * rp.origin.v[2];
     if (approx_eq_abs(a, 0, epsilon)) {
         if (approx_eq_abs(b, 0, epsilon)) {
             cone_intersect_caps(self, rp, xs);
             return;
         } else {
-            float t = -c / (2 * b);
+            real t = -c / (2 * b);
             append_hit(xs, t, K_CONE, self, sizeof *self);
             cone_intersect_caps(self, rp, xs);
             return;
         }
     }
-    float discriminant = b * b - 4 * a * c;
+    real discriminant = b * b - 4 * a * c;
     if (discriminant < 0) {
         cone_intersect_caps(self, rp, xs);
         return;
     }
-    float t0 = (-b - sqrtf(discriminant)) / (2 * a);
-    float t1 = (-b + sqrtf(discriminant)) / (2 * a);
-    if (t0 > t1) { float tmp = t0; t0 = t1; t1 = tmp; }
+    real t0 = (-b - R_SQRT(discriminant)) / (2 * a);
+    real t1 = (-b + R_SQRT(discriminant)) / (2 * a);
+    if (t0 > t1) { real tmp = t0; t0 = t1; t1 = tmp; }
 
-    float y0 = fmaf(t0, rp.direction.v[1], rp.origin.v[1]);
+    real y0 = R_FMA(t0, rp.direction.v[1], rp.origin.v[1]);
     if (self->minimum < y0 && y0 < self->maximum) append_hit(xs, t0, K_CONE, self, sizeof *self);
-    float y1 = fmaf(t1, rp.direction.v[1], rp.origin.v[1]);
+    real y1 = R_FMA(t1, rp.direction.v[1], rp.origin.v[1]);
     if (self->minimum < y1 && y1 < self->maximum) append_hit(xs, t1, K_CONE, self, sizeof *self);
 
     cone_intersect_caps(self, rp, xs);
@@ -757,13 +799,13 @@ static tuple cone_normal_at(const rt_cone* self, tuple world_point) { /* cone.zi
     mat4 inv = inverse(self->common_attrs.transform);
     tuple object_normal;
     tuple object_point = mul_tuple(inv, world_point);
-    float distance = object_point.v[0] * object_point.v[0] + object_point.v[2] * object_point.v[2];
+    real distance = object_point.v[0] * object_point.v[0] + object_point.v[2] * object_point.v[2];
     if (distance < self->maximum * self->maximum && object_point.v[1] >= self->maximum - epsilon) {
         object_normal = vector(0, 1, 0);
     } else if (distance < self->minimum * self->minimum && object_point.v[1] <= self->minimum + epsilon) {
         object_normal = vector(0, -1, 0);
     } else {
-        float y = (object_point.v[1] > 0) ? -sqrtf(distance) : sqrtf(distance);
+        real y = (object_point.v[1] > 0) ? -R_SQRT(distance) : R_SQRT(distance);
         object_normal = vector(object_point.v[0], y, object_point.v[2]);
     }
     tuple world_normal = mul_tuple(transpose(inv), object_normal);
@@ -777,16 +819,16 @@ static void triangle_intersect(const rt_triangle* self, ray r, xs_list* xs) { /*
     ray rp = ray_transform(r, inverse(self->common_attrs.transform));
     tuple e0 = tup_from(self->e0), e1 = tup_from(self->e1), p0 = tup_from(self->p0);
     tuple dir_cross_e1 = cross(rp.direction, e1);
-    float det = dot(e0, dir_cross_e1);
-    if (fabsf(det) < epsilon) return;
-    float f = 1.0f / det;
+    real det = dot(e0, dir_cross_e1);
+    if (R_FABS(det) < epsilon) return;
+    real f = 1.0f / det;
     tuple p0_to_origin = tsub(rp.origin, p0);
-    float u = f * dot(p0_to_origin, dir_cross_e1);
+    real u = f * dot(p0_to_origin, dir_cross_e1);
     if (u < 0 || u > 1) return;
     tuple origin_cross_e0 = cross(p0_to_origin, e0);
-    float v = f * dot(rp.direction, origin_cross_e0);
+    real v = f * dot(rp.direction, origin_cross_e0);
     if (v < 0 || (u + v) > 1) return;
-    float t = f * dot(e1, origin_cross_e0);
+    real t = f * dot(e1, origin_cross_e0);
     append_hit(xs, t, K_TRIANGLE, self, sizeof *self);
 }
 
@@ -800,11 +842,11 @@ static tuple triangle_normal_at(const rt_triangle* self, tuple world_point) { /*
 
 /* ------------------------------------------------------------ bounds.zig */
 
-static tminmax bounds_check_axis(float min, float max, float origin, float direction) { /* bounds.zig:160-175 */
-    float tmin_numerator = min - origin;
-    float tmax_numerator = max - origin;
-    float tmin, tmax;
-    if (fabsf(direction) >= epsilon) {
+static tminmax bounds_check_axis(real min, real max, real origin, real direction) { /* bounds.zig:160-175 */
+    real tmin_numerator = min - origin;
+    real tmax_numerator = max - origin;
+    real tmin, tmax;
+    if (R_FABS(direction) >= epsilon) {
         tmin = tmin_numerator / direction;
         tmax = tmax_numerator / direction;
     } else {
@@ -820,14 +862,14 @@ static int bounds_intersect(const rt_bounds* b, ray r) { /* bounds.zig:149-158 *
     tminmax x = bounds_check_axis(b->minimum[0], b->maximum[0], r.origin.v[0], r.direction.v[0]);
     tminmax y = bounds_check_axis(b->minimum[1], b->maximum[1], r.origin.v[1], r.direction.v[1]);
     tminmax z = bounds_check_axis(b->minimum[2], b->maximum[2], r.origin.v[2], r.direction.v[2]);
-    float tmin = fmaxf(x.tmin, fmaxf(y.tmin, z.tmin));
-    float tmax = fminf(x.tmax, fminf(y.tmax, z.tmax));
+    real tmin = R_FMAX(x.tmin, R_FMAX(y.tmin, z.tmin));
+    real tmax = R_FMIN(x.tmax, R_FMIN(y.tmax, z.tmax));
     return tmin <= tmax;
 }
 
 static void bset(rt_bounds* b, tuple mn, tuple mx) {
-    memcpy(b->minimum, mn.v, sizeof b->minimum);
-    memcpy(b->maximum, mx.v, sizeof b->maximum);
+    tup_store(b->minimum, mn);
+    tup_store(b->maximum, mx);
 }
 
 static void merge_point(rt_bounds* b, tuple p) { /* bounds.zig:114-117, lane-wise incl. w */
@@ -964,29 +1006,29 @@ static void group_intersect(const rt_group* g, mat4 g_transform, ray r, xs_list*
 
 static color col3(const float* p) { color c = {{p[0], p[1], p[2]}}; return c; }
 
-/* @mod(x, 2) == 0 with floored modulo: true exactly when fmodf(x, 2) is +-0. */
-static int mod2_is_zero(float x) { return fmodf(x, 2.0f) == 0.0f; }
+/* @mod(x, 2) == 0 with floored modulo: true exactly when R_FMOD(x, 2) is +-0. */
+static int mod2_is_zero(real x) { return R_FMOD(x, 2.0f) == 0.0f; }
 
 static color pattern_at(const rt_pattern* p, tuple pt) {
     color a = col3(p->a), b = col3(p->b);
     switch (p->color_map) {
     case RT_PATTERN_STRIPE: /* pattern.zig:33-35 */
-        return mod2_is_zero(floorf(pt.v[0])) ? a : b;
+        return mod2_is_zero(R_FLOOR(pt.v[0])) ? a : b;
     case RT_PATTERN_GRADIENT: { /* pattern.zig:37-41 */
-        float fraction = pt.v[0] - floorf(pt.v[0]);
+        real fraction = pt.v[0] - R_FLOOR(pt.v[0]);
         color r;
         for (int i = 0; i < 3; ++i) {
-            float distance = b.c[i] - a.c[i];
+            real distance = b.c[i] - a.c[i];
             r.c[i] = a.c[i] + distance * fraction;
         }
         return r;
     }
     case RT_PATTERN_RING: { /* pattern.zig:43-46 */
-        float c = floorf(sqrtf(pt.v[0] * pt.v[0] + pt.v[2] * pt.v[2]));
+        real c = R_FLOOR(R_SQRT(pt.v[0] * pt.v[0] + pt.v[2] * pt.v[2]));
         return mod2_is_zero(c) ? a : b;
     }
     default: { /* checker, pattern.zig:48-51 */
-        float c = floorf(pt.v[0]) + floorf(pt.v[1]) + floorf(pt.v[2]);
+        real c = R_FLOOR(pt.v[0]) + R_FLOOR(pt.v[1]) + R_FLOOR(pt.v[2]);
         return mod2_is_zero(c) ? a : b;
     }
     }
@@ -1013,17 +1055,17 @@ static color lighting(const rt_attrs* attrs, tuple light_position, color light_i
     for (int i = 0; i < 3; ++i) ambient.c[i] = effective_color.c[i] * material->ambient;
     if (in_shadow) return ambient;
 
-    float cos_light_normal = dot(light_direction, normal);
+    real cos_light_normal = dot(light_direction, normal);
     if (cos_light_normal < 0) {
         for (int i = 0; i < 3; ++i) diffuse.c[i] = specular.c[i] = 0;
     } else {
         for (int i = 0; i < 3; ++i) diffuse.c[i] = effective_color.c[i] * material->diffuse * cos_light_normal;
         tuple refl = reflect(tneg(light_direction), normal);
-        float cos_reflect_eye = dot(refl, eye);
+        real cos_reflect_eye = dot(refl, eye);
         if (cos_reflect_eye <= 0) {
             for (int i = 0; i < 3; ++i) specular.c[i] = 0;
         } else {
-            float factor = m_pow(cos_reflect_eye, material->shininess);
+            real factor = m_pow(cos_reflect_eye, material->shininess);
             for (int i = 0; i < 3; ++i) specular.c[i] = light_intensity.c[i] * material->specular * factor;
         }
     }
@@ -1034,10 +1076,10 @@ static color lighting(const rt_attrs* attrs, tuple light_position, color light_i
 /* ------------------------------------------------------ intersection.zig */
 
 typedef struct { /* intersection.zig:30-41 */
-    float t;
+    real t;
     rt_attrs shape_attrs;
     tuple point, eye, normal;
-    float n1, n2;
+    real n1, n2;
     tuple reflect;
 } computation;
 
@@ -1099,15 +1141,15 @@ static computation prepare_computations_for_refraction(const intersection* i, ra
     return comps;
 }
 
-static float schlick(const computation* comps) { /* intersection.zig:161-180 */
-    float r0 = (comps->n1 - comps->n2) / (comps->n1 + comps->n2);
+static real schlick(const computation* comps) { /* intersection.zig:161-180 */
+    real r0 = (comps->n1 - comps->n2) / (comps->n1 + comps->n2);
     r0 *= r0;
-    float cosv = dot(comps->eye, comps->normal);
+    real cosv = dot(comps->eye, comps->normal);
     if (comps->n1 > comps->n2) {
-        float n = comps->n1 / comps->n2;
-        float sin2_t = n * n * (1.0f - cosv * cosv);
+        real n = comps->n1 / comps->n2;
+        real sin2_t = n * n * (1.0f - cosv * cosv);
         if (sin2_t > 1.0f) return 1.0f;
-        cosv = sqrtf(1.0f - sin2_t);
+        cosv = R_SQRT(1.0f - sin2_t);
     }
     return r0 + (1 - r0) * m_pow(1 - cosv, 5);
 }
@@ -1138,7 +1180,7 @@ static color color_at_internal(ctx* c, ray r, unsigned remaining);
 static int is_shadowed(ctx* c, tuple p) { /* world.zig:97-120 */
     c->counts.shadow++;
     tuple v = tsub(tup_from(c->world->light_position), p);
-    float distance = magnitude(v);
+    real distance = magnitude(v);
     tuple direction = normalize(v);
     ray shadow_ray = {p, direction};
     xs_list xs = {0, 0, 0};
@@ -1154,7 +1196,7 @@ static int is_shadowed(ctx* c, tuple p) { /* world.zig:97-120 */
  * switch only so the golden tests can show that the shipped images were
  * rendered by an older revision that offset by a smaller epsilon (see
  * tests/test_oracle_golden.py); v1 is 100 and that is the default. */
-static float over_eps_factor = 100.0f;
+static real over_eps_factor = 100.0f;
 EXPORT void oracle_set_over_eps_factor(float f) { over_eps_factor = f; }
 /* Golden-provenance switch, default off (= v1): evaluate Phong at comps.point
  * instead of over_point.  v1 lights at over_point (world.zig:57-63); the shipped
@@ -1182,11 +1224,11 @@ static color refracted_color_internal(ctx* c, const computation* comps, unsigned
     color black = {{0, 0, 0}};
     if (remaining == 0) return black;
     if (comps->shape_attrs.material.transparency == 0) return black;
-    float n_ratio = comps->n1 / comps->n2;
-    float cos_i = dot(comps->eye, comps->normal);
-    float sin2_t = (n_ratio * n_ratio) * (1 - cos_i * cos_i);
+    real n_ratio = comps->n1 / comps->n2;
+    real cos_i = dot(comps->eye, comps->normal);
+    real sin2_t = (n_ratio * n_ratio) * (1 - cos_i * cos_i);
     if (sin2_t > 1) return black;
-    float cos_t = sqrtf(1.0f - sin2_t);
+    real cos_t = R_SQRT(1.0f - sin2_t);
     ray refract_ray = {
         tsub(comps->point, tmuls(comps->normal, epsilon * over_eps_factor)),
         tsub(tmuls(comps->normal, n_ratio * cos_i - cos_t), tmuls(comps->eye, n_ratio)),
@@ -1207,7 +1249,7 @@ static color shade_hit_internal(ctx* c, const computation* comps, unsigned remai
     const rt_material* material = &comps->shape_attrs.material;
     color out;
     if (material->reflective > 0 && material->transparency > 0) {
-        float reflectance = schlick(comps);
+        real reflectance = schlick(comps);
         for (int i = 0; i < 3; ++i)
             out.c[i] = surface.c[i] + reflected.c[i] * reflectance + refracted.c[i] * (1.0f - reflectance);
         return out;
@@ -1270,10 +1312,10 @@ EXPORT void oracle_camera(uint32_t horizontal_size, uint32_t vertical_size, floa
 }
 
 static ray ray_for_pixel(const rt_camera* c, uint32_t px, uint32_t py) { /* camera.zig:70-82 */
-    float x_offset = ((float)px + 0.5f) * c->pixel_size;
-    float y_offset = ((float)py + 0.5f) * c->pixel_size;
-    float world_x = c->half_width - x_offset;
-    float world_y = c->half_height - y_offset;
+    real x_offset = ((real)px + 0.5f) * c->pixel_size;
+    real y_offset = ((real)py + 0.5f) * c->pixel_size;
+    real world_x = c->half_width - x_offset;
+    real world_y = c->half_height - y_offset;
     tuple pixel = mul_tuple(inverse(c->transform), point(world_x, world_y, -1));
     tuple origin = mul_tuple(inverse(c->transform), point(0, 0, 0));
     tuple direction = normalize(tsub(pixel, origin));
@@ -1366,8 +1408,8 @@ EXPORT void oracle_color_at(const rt_world* world, const rt_ray* r, float rgb[3]
 
 EXPORT void oracle_ray_for_pixel(const rt_camera* c, uint32_t px, uint32_t py, rt_ray* out) {
     ray r = ray_for_pixel(c, px, py);
-    memcpy(out->origin, r.origin.v, sizeof out->origin);
-    memcpy(out->direction, r.direction.v, sizeof out->direction);
+    tup_store(out->origin, r.origin);
+    tup_store(out->direction, r.direction);
 }
 
 /* canvas.zig:42-50 — one pixel channel as toPPM prints it. */
@@ -1382,7 +1424,7 @@ EXPORT int oracle_ppm_byte(float c) {
 EXPORT void oracle_mat_mul(const rt_mat4* a, const rt_mat4* b, rt_mat4* out) { *out = mul_matrix(*a, *b); }
 EXPORT void oracle_mat_mul_tuple(const rt_mat4* a, const float b[4], float out[4]) {
     tuple r = mul_tuple(*a, tup_from(b));
-    memcpy(out, r.v, sizeof r.v);
+    tup_store(out, r);
 }
 EXPORT void oracle_mat_transpose(const rt_mat4* a, rt_mat4* out) { *out = transpose(*a); }
 EXPORT float oracle_mat_determinant(const rt_mat4* a) { return determinant(*a); }
@@ -1425,16 +1467,16 @@ EXPORT void oracle_mat_shearing(float xy, float xz, float yx, float yz, float zx
 EXPORT float oracle_tup_dot(const float a[4], const float b[4]) { return dot(tup_from(a), tup_from(b)); }
 EXPORT void oracle_tup_cross(const float a[4], const float b[4], float out[4]) {
     tuple r = cross(tup_from(a), tup_from(b));
-    memcpy(out, r.v, sizeof r.v);
+    tup_store(out, r);
 }
 EXPORT float oracle_tup_magnitude(const float a[4]) { return magnitude(tup_from(a)); }
 EXPORT void oracle_tup_normalize(const float a[4], float out[4]) {
     tuple r = normalize(tup_from(a));
-    memcpy(out, r.v, sizeof r.v);
+    tup_store(out, r);
 }
 EXPORT void oracle_tup_reflect(const float a[4], const float n[4], float out[4]) {
     tuple r = reflect(tup_from(a), tup_from(n));
-    memcpy(out, r.v, sizeof r.v);
+    tup_store(out, r);
 }
 EXPORT int oracle_tup_equal(const float a[4], const float b[4]) { return tup_equal(tup_from(a), tup_from(b)); }
 EXPORT int oracle_bounds_intersect(const rt_bounds* b, const rt_ray* r) {
@@ -1455,10 +1497,10 @@ EXPORT void oracle_triangle_init(const float p0[4], const float p1[4], const flo
     tuple e0 = tsub(b, a);
     tuple e1 = tsub(c, a);
     tuple n = normalize(cross(e1, e0));
-    memcpy(out->p0, a.v, 16);
-    memcpy(out->p1, b.v, 16);
-    memcpy(out->p2, c.v, 16);
-    memcpy(out->e0, e0.v, 16);
-    memcpy(out->e1, e1.v, 16);
-    memcpy(out->normal, n.v, 16);
+    tup_store(out->p0, a);
+    tup_store(out->p1, b);
+    tup_store(out->p2, c);
+    tup_store(out->e0, e0);
+    tup_store(out->e1, e1);
+    tup_store(out->normal, n);
 }

@@ -59,7 +59,7 @@ static void set_color(rt_material* m, float r, float g, float b) { m->color[0] =
 
 static void set_light(oracle_scene* s, float x, float y, float z, float r, float g, float b) {
     tuple p = point(x, y, z);
-    memcpy(s->world.light_position, p.v, 16);
+    tup_store(s->world.light_position, p);
     s->world.light_intensity[0] = r;
     s->world.light_intensity[1] = g;
     s->world.light_intensity[2] = b;
@@ -68,7 +68,9 @@ static void set_light(oracle_scene* s, float x, float y, float z, float r, float
 static void set_camera(oracle_scene* s, uint32_t w, uint32_t h, uint32_t dw, uint32_t dh, float fov,
                        tuple from, tuple to, tuple up) {
     if (w == 0 || h == 0) { w = dw; h = dh; }
-    oracle_camera(w, h, fov, from.v, to.v, up.v, &s->camera);
+    float f4[4], t4[4], u4[4];
+    tup_store(f4, from); tup_store(t4, to); tup_store(u4, up);
+    oracle_camera(w, h, fov, f4, t4, u4, &s->camera);
 }
 
 static void finish(oracle_scene* s, uint32_t ns, uint32_t np, uint32_t ncu, uint32_t ncy, uint32_t nco, uint32_t nt) {
@@ -284,7 +286,9 @@ EXPORT oracle_scene* oracle_sample(const char* name, uint32_t w, uint32_t h) {
         set_camera(s, w, h, 1024, 1024, (float)(PI / 3.0), point(0, 1.5f, -5), point(0, 1, 0), vector(0, 1, 0));
     } else if (!strcmp(name, "skewed_triangle")) { /* samples/skewed_triangle.zig */
         tuple p0 = point(-5, -5, 10), p1 = point(0, 2.5f, 0), p2 = point(5, -5, 3);
-        oracle_triangle_init(p0.v, p1.v, p2.v, &s->triangles[0]);
+        float q0[4], q1[4], q2[4];
+        tup_store(q0, p0); tup_store(q1, p1); tup_store(q2, p2);
+        oracle_triangle_init(q0, q1, q2, &s->triangles[0]);
         s->triangles[0].common_attrs = default_attrs();
         set_color(&s->triangles[0].common_attrs.material, 1, 1, 0.25f);
         s->triangles[0].common_attrs.material.ambient = 0.5f;
