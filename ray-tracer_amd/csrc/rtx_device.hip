@@ -228,6 +228,14 @@ RTX_HD V4 mul_mat_t(const float* m, V4 b) {
               m[3] * b.x + m[7] * b.y + m[11] * b.z + m[15] * b.w);
 }
 
+// The same three products for an inverse whose upper-left 3x3 block is diagonal (scalings and
+// translations only — most analytic shapes): the dropped terms are exact zeros (0 * finite), and
+// adding an exact zero changes nothing but, possibly, the sign of a zero result, which no consumer
+// can observe (every division on the path is guarded against a zero divisor, comparisons and
+// floor/sqrt treat both zeros alike).  Canonical-w kernels only.
+RTX_HD V4 mul_point_diag(const float* m, V4 b) { return v4(m[0] * b.x + m[3], m[5] * b.y + m[7], m[10] * b.z + m[11], 1.0f); }
+RTX_HD V4 mul_dir_diag(const float* m, V4 b) { return v4(m[0] * b.x, m[5] * b.y, m[10] * b.z, 0.0f); }
+
 // std.math.approxEqAbs(f32, x, 0, eps)
 __device__ __forceinline__ bool approx_zero(float x) {
     if (x == 0.0f) return true;
@@ -267,20 +275,22 @@ struct ClosestVisitor {
     // Ties go to the lowest insertion index for the hit and to the highest for the predecessor.
     // The world/group walk offers shapes in insertion order (ORDERED): a strict compare is
     // enough there.  The BVH offers triangles in tree order, so it compares the index too.
+    // Written as selects, not branches: inside the divergent shape tests hipcc turned the `if`
+    // form into exec-mask regions whose phi copies kept three register copies of (t, idx) alive
+    // and cost ~25 v_mov per sphere test (a VALU instruction is 4 SIMD cycles whatever it does).
     template <bool ORDERED>
     RTX_HD void hit(float t, uint32_t s) {
-        if (t >= 0.0f && (c.idx == kNone || t < c.t || (!ORDERED && t == c.t && s < c.idx))) {
-            c.t = t;
-            c.idx = s;
-        }
+        const bool better = (t >= 0.0f) & ((c.idx == kNone) | (t < c.t) | (!ORDERED & (t == c.t) & (s < c.idx)));
+        c.t = better ? t : c.t;
+        c.idx = better ? s : c.idx;
     }
     template <bool ORDERED>
     RTX_HD void pred(float t, uint32_t s) {
-        if (TRACK && t < 0.0f &&
-            (c.pred_idx == kNone || (ORDERED ? t >= c.pred_t : (t > c.pred_t || (t == c.pred_t && s > c.pred_idx))))) {
-            c.pred_t = t;
-            c.pred_idx = s;
-        }
+        if (!TRACK) return;
+        const bool later = ORDERED ? (t >= c.pred_t) : ((t > c.pred_t) | ((t == c.pred_t) & (s > c.pred_idx)));
+        const bool better = (t < 0.0f) & ((c.pred_idx == kNone) | later);
+        c.pred_t = better ? t : c.pred_t;
+        c.pred_idx = better ? s : c.pred_idx;
     }
     static constexpr bool kTrack = TRACK;
     RTX_HD void visited_node() {}     // statistics hooks of the BVH walk (rtx_bvh_selftest counts with them)
@@ -304,10 +314,9 @@ struct PredVisitor {
     RTX_HD void hit(float, uint32_t) {}
     template <bool ORDERED>
     RTX_HD void pred(float t, uint32_t s) {
-        if (t < 0.0f && (pred_idx == kNone || t > pred_t || (t == pred_t && s > pred_idx))) {
-            pred_t = t;
-            pred_idx = s;
-        }
+        const bool better = (t < 0.0f) & ((pred_idx == kNone) | (t > pred_t) | ((t == pred_t) & (s > pred_idx)));
+        pred_t = better ? t : pred_t;
+        pred_idx = better ? s : pred_idx;
     }
     static constexpr bool kBvhPred = true;
     RTX_HD void visited_node() {}
@@ -323,9 +332,7 @@ struct ShadowVisitor {
     float distance;
     bool found;
     template <bool ORDERED>
-    __device__ __forceinline__ void hit(float t, uint32_t) {
-        if (t >= 0.0f && t < distance) found = true;
-    }
+    __device__ __forceinline__ void hit(float t, uint32_t) { found = found | ((t >= 0.0f) & (t < distance)); }
     template <bool ORDERED>
     __device__ __forceinline__ void pred(float, uint32_t) {}
     static constexpr bool kTrack = false;
@@ -378,9 +385,10 @@ template <class V>
 __device__ __forceinline__ void offer2(V& v, uint32_t s, bool n1_visible, float t0, float t1) {
     v.template hit<true>(t0, s);
     v.template hit<true>(t1, s);
-    if (V::kTrack && n1_visible && t0 != t1) {  // equal roots cancel each other
-        v.template pred<true>(t0, s);
-        v.template pred<true>(t1, s);
+    if (V::kTrack && n1_visible) {  // wave-uniform flag; equal roots cancel each other: offer NaN (never a predecessor) then
+        const bool distinct = t0 != t1;
+        v.template pred<true>(distinct ? t0 : NAN, s);
+        v.template pred<true>(distinct ? t1 : NAN, s);
     }
 }
 // Up to four roots with validity flags (cylinder / cone: two walls, two caps).
@@ -403,6 +411,7 @@ __device__ __forceinline__ void offer_roots(V& v, uint32_t s, bool n1_visible, c
 }
 
 constexpr uint32_t kShapeIdentity = 1u << 8;  // library-internal: the inverse is exactly the identity
+constexpr uint32_t kShapeDiagonal = 1u << 9;  // library-internal: the inverse is diag(a, b, c) plus a translation, last row (0, 0, 0, 1)
 
 // Triangle.intersect (src/triangle.zig:32-50, Moller-Trumbore) on the object-space ray.
 // cross() has w = 0, so the w lanes of e0 / e1 / p0_to_origin only ever add an exact zero to
@@ -428,7 +437,12 @@ RTX_HD bool triangle_root(V4 ro, V4 rd, const float* p0, const float* e0, const 
 template <bool C, class V>
 __device__ __forceinline__ void intersect_shape(V& v, const RT_CONST rtx_shape& sh, uint32_t s, V4 o, V4 d) {
     V4 ro = o, rd = d;
-    if (!(sh.flags & kShapeIdentity)) {  // x * identity is x (up to the sign of a zero): skip it
+    if (C && (sh.flags & kShapeDiagonal)) {  // wave-uniform branch: 9 instead of 33 operations
+        const float inv[16] = {sh.inverse[0], 0.0f, 0.0f, sh.inverse[3], 0.0f, sh.inverse[5], 0.0f, sh.inverse[7],
+                               0.0f, 0.0f, sh.inverse[10], sh.inverse[11], 0.0f, 0.0f, 0.0f, 1.0f};
+        ro = mul_point_diag(inv, o);
+        rd = mul_dir_diag(inv, d);
+    } else if (!(sh.flags & kShapeIdentity)) {  // x * identity is x (up to the sign of a zero): skip it
         float inv[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) inv[k] = sh.inverse[k];
@@ -669,13 +683,27 @@ __device__ __forceinline__ void traverse_pred(PredVisitor& v, const Params& p, V
 // ------------------------------------------------------------------------ shading
 
 // Shape.normalAt for the hit shape (per-lane record).
+// world -> object point for the per-lane hit shape; the diagonal form when the shape allows it
+// (a per-lane branch: waves whose hits all sit on scaled / translated shapes skip the general one).
+template <bool C>
+__device__ __forceinline__ V4 to_object(const rtx_shape& sh, V4 world_point) {
+    if (sh.flags & kShapeIdentity) return world_point;
+    if (C && (sh.flags & kShapeDiagonal)) return mul_point_diag(sh.inverse, world_point);
+    return mul_point<C>(sh.inverse, world_point);
+}
+template <bool C>
+__device__ __forceinline__ V4 normal_to_world(const rtx_shape& sh, V4 n) {
+    if (sh.flags & kShapeIdentity) return n;
+    if (C && (sh.flags & kShapeDiagonal)) return mul_dir_diag(sh.inverse, n);  // a diagonal block is its own transpose
+    return mul_mat_t<C>(sh.inverse, n);
+}
+
 template <bool C>
 __device__ __forceinline__ V4 normal_at(const rtx_shape& sh, V4 world_point) {
-    const float* inv = sh.inverse;
     V4 object_normal;
     switch (sh.type) {
     case RTX_SPHERE: {  // src/sphere.zig:56-82
-        const V4 object_point = mul_point<C>(inv, world_point);
+        const V4 object_point = to_object<C>(sh, world_point);
         object_normal = sub(object_point, v4(0.0f, 0.0f, 0.0f, 1.0f));
         break;
     }
@@ -683,16 +711,16 @@ __device__ __forceinline__ V4 normal_at(const rtx_shape& sh, V4 world_point) {
         object_normal = v4(0.0f, 1.0f, 0.0f, 0.0f);
         break;
     case RTX_CUBE: {  // src/cube.zig:28-44 — w is NOT reset before normalising
-        const V4 object_point = mul_point<C>(inv, world_point);
+        const V4 object_point = to_object<C>(sh, world_point);
         const float x = fabsf(object_point.x), y = fabsf(object_point.y), z = fabsf(object_point.z);
         const float maxc = fmaxf(x, fmaxf(y, z));
         if (maxc == x) object_normal = v4(object_point.x, 0.0f, 0.0f, 0.0f);
         else if (maxc == y) object_normal = v4(0.0f, object_point.y, 0.0f, 0.0f);
         else object_normal = v4(0.0f, 0.0f, object_point.z, 0.0f);
-        return normalize<C>(mul_mat_t<C>(inv, object_normal));
+        return normalize<C>(normal_to_world<C>(sh, object_normal));
     }
     case RTX_CYLINDER: {  // src/cylinder.zig:73-92
-        const V4 object_point = mul_point<C>(inv, world_point);
+        const V4 object_point = to_object<C>(sh, world_point);
         const float distance = object_point.x * object_point.x + object_point.z * object_point.z;
         if (distance < 1.0f && object_point.y >= sh.maximum - kEpsilon) object_normal = v4(0.0f, 1.0f, 0.0f, 0.0f);
         else if (distance < 1.0f && object_point.y <= sh.minimum + kEpsilon) object_normal = v4(0.0f, -1.0f, 0.0f, 0.0f);
@@ -700,7 +728,7 @@ __device__ __forceinline__ V4 normal_at(const rtx_shape& sh, V4 world_point) {
         break;
     }
     case RTX_CONE: {  // src/cone.zig:84-105
-        const V4 object_point = mul_point<C>(inv, world_point);
+        const V4 object_point = to_object<C>(sh, world_point);
         const float distance = object_point.x * object_point.x + object_point.z * object_point.z;
         if (distance < sh.maximum * sh.maximum && object_point.y >= sh.maximum - kEpsilon) {
             object_normal = v4(0.0f, 1.0f, 0.0f, 0.0f);
@@ -716,7 +744,7 @@ __device__ __forceinline__ V4 normal_at(const rtx_shape& sh, V4 world_point) {
         object_normal = v4(sh.normal[0], sh.normal[1], sh.normal[2], sh.normal[3]);
         break;
     }
-    V4 world_normal = mul_mat_t<C>(inv, object_normal);
+    V4 world_normal = normal_to_world<C>(sh, object_normal);
     world_normal.w = 0.0f;
     return normalize<C>(world_normal);
 }
@@ -731,7 +759,7 @@ struct Color {
 // Pattern.atShape (src/pattern.zig:23-51)
 template <bool C>
 __device__ __forceinline__ Color pattern_at_shape(const rtx_pattern& pat, const rtx_shape& sh, V4 world_point) {
-    const V4 object_point = mul_point<C>(sh.inverse, world_point);
+    const V4 object_point = to_object<C>(sh, world_point);
     const V4 pt = mul_point<C>(pat.inverse, object_point);  // only x, y, z are read
     const Color a{pat.a[0], pat.a[1], pat.a[2]}, b{pat.b[0], pat.b[1], pat.b[2]};
     switch (pat.color_map) {
@@ -1487,6 +1515,10 @@ void build_bvhs(std::vector<rtx_shape>& shapes, std::vector<rtx_node>& nodes, st
         for (int k = 0; k < 16; ++k) ident = ident && sh.inverse[k] == kIdentity[k];
         sh.flags &= 0xFFu;  // bits above are the library's
         if (ident) sh.flags |= kShapeIdentity;
+        static const int kOffDiagonal[6] = {1, 2, 4, 6, 8, 9};
+        bool diag = !ident && sh.inverse[12] == 0.0f && sh.inverse[13] == 0.0f && sh.inverse[14] == 0.0f && sh.inverse[15] == 1.0f;
+        for (int k : kOffDiagonal) diag = diag && sh.inverse[k] == 0.0f;
+        if (diag) sh.flags |= kShapeDiagonal;
     }
     for (rtx_node& n : nodes) n.reserved[0] = n.reserved[1] = 0;
     linear = nodes;
