@@ -436,20 +436,32 @@ RTX_HD bool triangle_root(V4 ro, V4 rd, const float* p0, const float* e0, const 
 // (src/ray.zig:13-18) with all four lanes kept.
 template <bool C, class V>
 __device__ __forceinline__ void intersect_shape(V& v, const RT_CONST rtx_shape& sh, uint32_t s, V4 o, V4 d) {
-    V4 ro = o, rd = d;
-    if (C && (sh.flags & kShapeDiagonal)) {  // wave-uniform branch: 9 instead of 33 operations
-        const float inv[16] = {sh.inverse[0], 0.0f, 0.0f, sh.inverse[3], 0.0f, sh.inverse[5], 0.0f, sh.inverse[7],
-                               0.0f, 0.0f, sh.inverse[10], sh.inverse[11], 0.0f, 0.0f, 0.0f, 1.0f};
-        ro = mul_point_diag(inv, o);
-        rd = mul_dir_diag(inv, d);
-    } else if (!(sh.flags & kShapeIdentity)) {  // x * identity is x (up to the sign of a zero): skip it
-        float inv[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) inv[k] = sh.inverse[k];
-        ro = mul_point<C>(inv, o);
-        rd = mul_dir<C>(inv, d);
-    }
     const bool n1_visible = !(sh.flags & RTX_SHAPE_N1_INVISIBLE);
+    // r.transform(inverse), src/ray.zig:13-18 (all branches wave-uniform)
+    auto to_object_space = [&](V4& ro, V4& rd) {
+        ro = o;
+        rd = d;
+        if (C && (sh.flags & kShapeDiagonal)) {  // 9 instead of 33 operations
+            const float inv[16] = {sh.inverse[0], 0.0f, 0.0f, sh.inverse[3], 0.0f, sh.inverse[5], 0.0f, sh.inverse[7],
+                                   0.0f, 0.0f, sh.inverse[10], sh.inverse[11], 0.0f, 0.0f, 0.0f, 1.0f};
+            ro = mul_point_diag(inv, o);
+            rd = mul_dir_diag(inv, d);
+        } else if (!(sh.flags & kShapeIdentity)) {  // x * identity is x (up to the sign of a zero): skip it
+            float inv[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) inv[k] = sh.inverse[k];
+            ro = mul_point<C>(inv, o);
+            rd = mul_dir<C>(inv, d);
+        }
+    };
+    if (sh.type == RTX_PLANE) {  // src/plane.zig:13-28 — reads only the y row of the object-space ray,
+        V4 ro, rd;               // so the transform sits inside the branch and its x / z rows fall away
+        to_object_space(ro, rd);
+        if (!(fabsf(rd.y) < kEpsilon)) offer1(v, s, n1_visible, -ro.y / rd.y);
+        return;
+    }
+    V4 ro, rd;
+    to_object_space(ro, rd);
 
     switch (sh.type) {
     case RTX_SPHERE: {  // src/sphere.zig:11-54
@@ -462,10 +474,6 @@ __device__ __forceinline__ void intersect_shape(V& v, const RT_CONST rtx_shape& 
             const float sq = sqrtf(discriminant);
             offer2(v, s, n1_visible, (-b - sq) / (2.0f * a), (-b + sq) / (2.0f * a));
         }
-        return;
-    }
-    case RTX_PLANE: {  // src/plane.zig:13-28
-        if (!(fabsf(rd.y) < kEpsilon)) offer1(v, s, n1_visible, -ro.y / rd.y);
         return;
     }
     case RTX_CUBE: {  // src/cube.zig:11-26
@@ -779,15 +787,15 @@ __device__ __forceinline__ Color pattern_at_shape(const rtx_pattern& pat, const 
 // Material.lighting (src/material.zig:40-102)
 template <bool C>
 __device__ __forceinline__ Color lighting(const Params& p, const rtx_pattern* patterns, const rtx_material& m,
-                                          const rtx_shape& sh, V4 point, V4 eye, V4 normal, bool in_shadow) {
+                                          const rtx_shape& sh, V4 point, V4 light_direction, V4 eye, V4 normal, bool in_shadow) {
     Color color;
     if (m.pattern >= 0) color = pattern_at_shape<C>(patterns[m.pattern], sh, point);
     else color = Color{m.color[0], m.color[1], m.color[2]};
 
     const Color li{p.light_intensity[0], p.light_intensity[1], p.light_intensity[2]};
     const Color effective{color.r * li.r, color.g * li.g, color.b * li.b};
-    const V4 lp = v4(p.light_position[0], p.light_position[1], p.light_position[2], p.light_position[3]);
-    const V4 light_direction = normalize<C>(sub(lp, point));
+    // light_direction = normalize(light.position - point) (src/material.zig:58) comes from the caller:
+    // the shadow ray's direction is the same expression on the same point (src/world.zig:100-106).
     const Color ambient{effective.r * m.ambient, effective.g * m.ambient, effective.b * m.ambient};
     if (in_shadow) return ambient;
 
@@ -796,7 +804,8 @@ __device__ __forceinline__ Color lighting(const Params& p, const rtx_pattern* pa
     if (!(cos_light_normal < 0.0f)) {
         diffuse = Color{effective.r * m.diffuse * cos_light_normal, effective.g * m.diffuse * cos_light_normal,
                         effective.b * m.diffuse * cos_light_normal};
-        const V4 refl = reflect<C>(neg(light_direction), normal);
+        // reflect(-L, N) = -L - N * dot(-L, N) * 2 (src/tuple.zig:58-77); dot(-L, N) is exactly -dot(L, N)
+        const V4 refl = sub(neg(light_direction), muls(muls(normal, -cos_light_normal), 2.0f));
         const float cos_reflect_eye = dot<C>(refl, eye);
         if (!(cos_reflect_eye <= 0.0f)) {
             const float factor = rt::zmath::pow_f32(cos_reflect_eye, m.shininess);
@@ -804,21 +813,6 @@ __device__ __forceinline__ Color lighting(const Params& p, const rtx_pattern* pa
         }
     }
     return Color{ambient.r + diffuse.r + specular.r, ambient.g + diffuse.g + specular.g, ambient.b + diffuse.b + specular.b};
-}
-
-// schlick (src/intersection.zig:161-180)
-template <bool C>
-__device__ __forceinline__ float schlick(float n1, float n2, V4 eye, V4 normal) {
-    float r0 = (n1 - n2) / (n1 + n2);
-    r0 *= r0;
-    float cosv = dot<C>(eye, normal);
-    if (n1 > n2) {
-        const float n = n1 / n2;
-        const float sin2_t = n * n * (1.0f - cosv * cosv);
-        if (sin2_t > 1.0f) return 1.0f;
-        cosv = sqrtf(1.0f - sin2_t);
-    }
-    return r0 + (1.0f - r0) * rt::zmath::pow_f32(1.0f - cosv, 5.0f);
 }
 
 // shadeHitInternal's final expression (src/world.zig:71-78)
@@ -1085,13 +1079,21 @@ __attribute__((amdgpu_waves_per_eu((BVH || !C) ? RTX_WAVES_PER_EU : RTX_WAVES_PE
         // prepareComputations (src/intersection.zig:43-90) and the shadow ray
         // (src/world.zig:55,97-106), per lane.
         V4 point = o, normal = d, over_point = o, shadow_dir = d;
-        float n1 = 1.0f, n2 = 1.0f, shadow_distance = 0.0f;
+        float n1 = 1.0f, n2 = 1.0f, shadow_distance = 0.0f, cos_i = 0.0f;
         if (is_hit) {
             ++local_hits;
             const rtx_shape& sh = tab.shapes[cv.c.idx];
             point = add(o, muls(d, cv.c.t));  // ray.position, src/ray.zig:9-11
             normal = normal_at<C>(sh, point);
-            if (dot<C>(normal, neg(d)) < 0.0f) normal = neg(normal);
+            // dot(normal, eye) decides the flip (src/intersection.zig:79); the dots the shading takes
+            // later with the final normal — dot(eye, normal), dot(ray.direction, normal) — are this
+            // value or its exact negation (products commute, negation commutes with rounding).
+            const float dn = dot<C>(normal, neg(d));
+            cos_i = dn;
+            if (dn < 0.0f) {
+                normal = neg(normal);
+                cos_i = -dn;
+            }
             // n1 / n2 (src/intersection.zig:92-159, see Closest above)
             if (TRACK && cv.c.pred_idx != kNone) n1 = tab.materials[tab.shapes[cv.c.pred_idx].material].refractive_index;
             n2 = tab.materials[sh.material].refractive_index;
@@ -1119,33 +1121,47 @@ __attribute__((amdgpu_waves_per_eu((BVH || !C) ? RTX_WAVES_PER_EU : RTX_WAVES_PE
             const rtx_shape& sh = tab.shapes[cv.c.idx];
             const rtx_material& m = tab.materials[sh.material];
             const V4 eye = neg(d);
-            reflectv = reflect<C>(d, normal);
+            // reflect(ray.direction, normal) (src/intersection.zig:88): dot(direction, normal) == -cos_i
+            reflectv = sub(d, muls(muls(normal, -cos_i), 2.0f));
             reflective = m.reflective;
             transparency = m.transparency;
             local_patterned += m.pattern >= 0 ? 1u : 0u;
             local_transparent += (m.transparency != 0.0f && remaining != 0u) ? 1u : 0u;  // refraction set-up evaluated
             // shadeHitInternal (src/world.zig:54-79): Phong is evaluated at over_point.
-            surface = lighting<C>(p, tab.patterns, m, sh, over_point, eye, normal, sv.found);
+            surface = lighting<C>(p, tab.patterns, m, sh, over_point, shadow_dir, eye, normal, sv.found);
             // reflectedColorInternal (src/world.zig:126-143)
             spawn_reflect = remaining != 0u && m.reflective != 0.0f;
-            // refractedColorInternal (src/world.zig:149-186)
-            if (remaining != 0u && m.transparency != 0.0f) {
-                const float n_ratio = n1 / n2;
-                const float cos_i = dot<C>(eye, normal);
+            // refractedColorInternal (src/world.zig:149-186) and schlick (src/intersection.zig:161-180)
+            // take the same n1 / n2, sin2_t and sqrt(1 - sin2_t): evaluated once for both.
+            const bool refracts = remaining != 0u && m.transparency != 0.0f;
+            use_schlick = m.reflective > 0.0f && m.transparency > 0.0f;
+            // At the depth limit the reflectance only weighs two black children: 0 * R and
+            // 0 * (1 - R) are 0 for any finite R, so a scene whose Schlick values are all
+            // finite (p.finite_schlick) need not evaluate it there.
+            const bool eval_schlick = use_schlick && (remaining != 0u || !p.finite_schlick);
+            const bool denser = n1 > n2;
+            float n_ratio = 1.0f, cos_t = 0.0f;
+            bool total_internal = false;
+            if (refracts || (eval_schlick && denser)) {
+                n_ratio = n1 / n2;
                 const float sin2_t = (n_ratio * n_ratio) * (1.0f - cos_i * cos_i);
-                if (!(sin2_t > 1.0f)) {
-                    const float cos_t = sqrtf(1.0f - sin2_t);
-                    spawn_refract = true;
-                    under_point = sub(point, muls(normal, p.over_eps));
-                    refract_dir = sub(muls(normal, n_ratio * cos_i - cos_t), muls(eye, n_ratio));
-                }
+                total_internal = sin2_t > 1.0f;
+                if (!total_internal) cos_t = sqrtf(1.0f - sin2_t);
             }
-            if (m.reflective > 0.0f && m.transparency > 0.0f) {
-                use_schlick = true;
-                // At the depth limit the reflectance only weighs two black children: 0 * R and
-                // 0 * (1 - R) are 0 for any finite R, so a scene whose Schlick values are all
-                // finite (p.finite_schlick) need not evaluate it there.
-                if (remaining != 0u || !p.finite_schlick) reflectance = schlick<C>(n1, n2, eye, normal);
+            if (refracts && !total_internal) {
+                spawn_refract = true;
+                under_point = sub(point, muls(normal, p.over_eps));
+                refract_dir = sub(muls(normal, n_ratio * cos_i - cos_t), muls(eye, n_ratio));
+            }
+            if (eval_schlick) {
+                if (denser && total_internal) {
+                    reflectance = 1.0f;
+                } else {
+                    float r0 = (n1 - n2) / (n1 + n2);
+                    r0 *= r0;
+                    const float cosv = denser ? cos_t : cos_i;
+                    reflectance = r0 + (1.0f - r0) * rt::zmath::pow_f32(1.0f - cosv, 5.0f);
+                }
             }
         }
 
