@@ -412,6 +412,7 @@ __device__ __forceinline__ void offer_roots(V& v, uint32_t s, bool n1_visible, c
 
 constexpr uint32_t kShapeIdentity = 1u << 8;  // library-internal: the inverse is exactly the identity
 constexpr uint32_t kShapeDiagonal = 1u << 9;  // library-internal: the inverse is diag(a, b, c) plus a translation, last row (0, 0, 0, 1)
+constexpr uint32_t kShapeWorldNormal = 1u << 10;  // library-internal: `normal` holds the finished world-space normal (planes, triangles)
 
 // Triangle.intersect (src/triangle.zig:32-50, Moller-Trumbore) on the object-space ray.
 // cross() has w = 0, so the w lanes of e0 / e1 / p0_to_origin only ever add an exact zero to
@@ -706,8 +707,23 @@ __device__ __forceinline__ V4 normal_to_world(const rtx_shape& sh, V4 n) {
     return mul_mat_t<C>(sh.inverse, n);
 }
 
+// Planes and triangles have one normal (src/plane.zig:30-46, src/triangle.zig:52-61): the scene
+// upload evaluates normalize(transpose(inverse) * n, w = 0) once per shape with these same f32
+// operations on the host (world_normal_of) and every hit reads the result.
+__host__ inline void world_normal_of(const rtx_shape& sh, float out[4]) {
+    V4 n = sh.type == RTX_PLANE ? v4(0.0f, 1.0f, 0.0f, 0.0f) : v4(sh.normal[0], sh.normal[1], sh.normal[2], sh.normal[3]);
+    V4 w = mul_mat_t<false>(sh.inverse, n);
+    w.w = 0.0f;
+    w = normalize<false>(w);
+    out[0] = w.x;
+    out[1] = w.y;
+    out[2] = w.z;
+    out[3] = w.w;
+}
+
 template <bool C>
 __device__ __forceinline__ V4 normal_at(const rtx_shape& sh, V4 world_point) {
+    if (sh.flags & kShapeWorldNormal) return v4(sh.normal[0], sh.normal[1], sh.normal[2], C ? 0.0f : sh.normal[3]);
     V4 object_normal;
     switch (sh.type) {
     case RTX_SPHERE: {  // src/sphere.zig:56-82
@@ -1535,6 +1551,12 @@ void build_bvhs(std::vector<rtx_shape>& shapes, std::vector<rtx_node>& nodes, st
         bool diag = !ident && sh.inverse[12] == 0.0f && sh.inverse[13] == 0.0f && sh.inverse[14] == 0.0f && sh.inverse[15] == 1.0f;
         for (int k : kOffDiagonal) diag = diag && sh.inverse[k] == 0.0f;
         if (diag) sh.flags |= kShapeDiagonal;
+        if (sh.type == RTX_PLANE || sh.type == RTX_TRIANGLE) {
+            float wn[4];
+            world_normal_of(sh, wn);
+            std::memcpy(sh.normal, wn, sizeof wn);
+            sh.flags |= kShapeWorldNormal;
+        }
     }
     for (rtx_node& n : nodes) n.reserved[0] = n.reserved[1] = 0;
     linear = nodes;
