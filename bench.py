@@ -51,9 +51,15 @@ SCENES = ["glass_spheres", "fresnel"]
 STRIP_ROWS = 16
 REHEARSE = os.environ.get("RTX_BENCH_REHEARSE") == "1"  # not a measurement mode; see main()
 EVENT_EVERY = 10  # timed steps whose kernel launches are bracketed by HIP events (roofline.avg_launch_ms)
-VALU_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz, one flop per VALU op: FMA
-                         # contraction is forbidden by parity, so mul and add issue separately
-                         # (the FMA/packed peak is 157.3 TFLOP/s; DESIGN.md "Roofline")
+VALU_PEAK_TFLOPS = 39.3  # 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz, one flop per VALU instruction: FMA
+                         # contraction is forbidden by parity, so a multiply and an add issue
+                         # separately, and an unpacked f32 VALU wave-instruction occupies its SIMD
+                         # for 4 cycles whatever it does — measured on the box, 4.06-4.23 cycles at
+                         # 6 waves per SIMD for mul/add, fma and cmp/cndmask alike
+                         # (tools/microbench/valu_rate.hip, profiles/r01_h_valu_rate.txt).  The spec's
+                         # 157.3 TFLOP/s is that rate x 2 (FMA) x 2 (v_pk_* packed pairs).
+VALU_PEAK_FMA_TFLOPS = 78.6     # same issue rate with every instruction an FMA (not reachable under the parity contract)
+VALU_PEAK_SPEC_TFLOPS = 157.3   # packed FMA, MI355X_MICROARCH.md "Peak FP32 (vector)"
 
 # SURVEY.md §8(d) flop table (add/sub/mul/div/sqrt = 1, fma = 2, pow = 1, compares = 0;
 # 4-lane dot = 7, mat-vec = 28).
@@ -286,10 +292,13 @@ def main():
                 "bound": "valu", "kernel": "k_trace_shade",
                 "achieved": achieved, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / VALU_PEAK_TFLOPS,
+                "frac_of_fma_peak": achieved / VALU_PEAK_FMA_TFLOPS, "frac_of_spec_peak": achieved / VALU_PEAK_SPEC_TFLOPS,
                 "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
                 "flops_per_launch": flops_per_launch, "avg_launch_ms": avg_ms, "launches": launches,
                 "share_of_step": (ms_trace / profiled_steps) / (dt / args.steps * 1e3) if dt > 0 and profiled_steps else None,
-                "note": "f32 VALU roofline (no MFMA: divergent per-lane scalar math); peak = non-FMA issue rate; "
+                "note": "f32 VALU roofline (no MFMA: divergent per-lane scalar math); peak = unfused, unpacked f32 issue rate, "
+                        "39.3 T lane-ops/s (measured 38.7: profiles/r01_h_valu_rate.txt); frac_of_fma_peak / frac_of_spec_peak "
+                        "price the same achieved figure against 78.6 (all-FMA) and 157.3 (packed FMA, the spec number); "
                         "rank 0's launches of every %d-th timed step, bracketed by HIP events on the render stream; "
                         "traffic = HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE) from the committed PMC pass "
                         "named in traffic_source" % EVENT_EVERY,
