@@ -72,8 +72,15 @@ def compose(*ms):
     return acc
 
 
+AXIS_ALIGNED = False  # random_transform() leaves the rotation out (see axis_aligned_world)
+
+
 def random_transform(rng, spread=2.0):
     t = translation(*[float(v) for v in rng.uniform(-spread, spread, 3)])
+    if AXIS_ALIGNED:
+        kind = int(rng.integers(0, 4))  # scale + translate, scale only, translate only, identity
+        s = scaling(*[float(v) for v in rng.uniform(0.3, 1.5, 3)])
+        return [compose(t, s), s, t, st.identity()][kind]
     r = compose(rotation("x", float(rng.uniform(-3, 3))), rotation("y", float(rng.uniform(-3, 3))),
                 rotation("z", float(rng.uniform(-3, 3))))
     s = scaling(*[float(v) for v in rng.uniform(0.3, 1.5, 3)])
@@ -162,6 +169,23 @@ def random_world(seed, n_shapes=8, groups=0, fancy=True):
     light = [float(v) for v in rng.uniform(-6, 6, 3)] + [1.0]
     light[1] = abs(light[1]) + 3
     w, keep = st.make_world(light, [float(v) for v in rng.uniform(0.6, 1.0, 3)], groups=glist, keep=keep, **shapes)
+    return w, keep
+
+
+def axis_aligned_world(seed, n_shapes=10):
+    """random_world with transforms made of scalings and translations only (and identities): the
+    shapes whose inverse has a diagonal 3x3 block, which the kernels transform in 9 operations.
+    Cubes are only scaled, so that the scene keeps w canonical and the diagonal forms actually run."""
+    global AXIS_ALIGNED
+    AXIS_ALIGNED = True
+    try:
+        w, keep = random_world(seed, n_shapes=n_shapes, groups=0)
+    finally:
+        AXIS_ALIGNED = False
+    for i in range(w.n_cubes):
+        m = w.cubes[i].common_attrs.transform
+        for r in range(3):
+            m.m[r][3] = 0.0
     return w, keep
 
 

@@ -76,6 +76,23 @@ def test_random_world_matches_oracle(seed):
     scene.close()
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_axis_aligned_world_matches_oracle(seed):
+    """Scaled / translated / untransformed shapes of every type: the diagonal-inverse ray transform, the
+    identity shortcuts and the per-shape world normals of planes and triangles, against the oracle's
+    full 4x4 arithmetic; the four-lane kernels (no diagonal form) must agree too."""
+    w, keep = su.axis_aligned_world(100 + seed, n_shapes=8 + seed)
+    cam = su.default_camera(96, 64)
+    ref, counts = o.render(cam, w)
+    scene = rta.Scene(w)
+    gpu, stats = scene.render(cam)
+    compare(gpu, ref, "axis-aligned world %d" % seed)
+    assert stats.rays_total == counts.total
+    full, _ = scene.render(cam, full_w=True)
+    compare(full, ref, "axis-aligned world %d (full_w)" % seed)
+    scene.close()
+
+
 def test_color_at_matches_oracle_including_rays_from_inside():
     s = rta.Sample("glass_spheres")
     scene = rta.Scene(s.world)
