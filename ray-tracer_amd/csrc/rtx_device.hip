@@ -391,21 +391,19 @@ __device__ __forceinline__ void offer2(V& v, uint32_t s, bool n1_visible, float 
         v.template pred<true>(distinct ? t1 : NAN, s);
     }
 }
-// Up to four roots with validity flags (cylinder / cone: two walls, two caps).
+// Up to four roots (cylinder / cone: two walls, two caps); a slot without a root holds NaN, which
+// is never a hit, never a predecessor and never equal to anything.
 template <class V>
-__device__ __forceinline__ void offer_roots(V& v, uint32_t s, bool n1_visible, const float* t, const bool* ok) {
+__device__ __forceinline__ void offer_roots(V& v, uint32_t s, bool n1_visible, const float* t) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-        if (ok[i]) v.template hit<true>(t[i], s);
+    for (int i = 0; i < 4; ++i) v.template hit<true>(t[i], s);
     if (V::kTrack && n1_visible) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            if (!ok[i]) continue;
-            int same = 0;
+            int same = 0;  // roots of this shape with exactly this t (itself included): pairs cancel
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (ok[j] && t[j] == t[i]) ++same;
-            if (same & 1) v.template pred<true>(t[i], s);
+            for (int j = 0; j < 4; ++j) same += (t[j] == t[i]) ? 1 : 0;
+            v.template pred<true>((same & 1) ? t[i] : NAN, s);
         }
     }
 }
@@ -435,8 +433,13 @@ RTX_HD bool triangle_root(V4 ro, V4 rd, const float* p0, const float* e0, const 
 // Shape.intersect for every shape type; `sh` is wave-uniform (scalar loads), the ray is
 // per lane.  o/d are the world-space ray; the object-space ray is r.transform(inverse)
 // (src/ray.zig:13-18) with all four lanes kept.
+// Shape of the code: the roots are computed under the divergent conditions (`active` — this lane
+// tests this shape at all — folded in) into temporaries that default to NaN, and the visitor is
+// then updated unconditionally with selects.  A NaN root changes nothing (not >= 0, not < 0), so
+// the visitor's registers are never written inside a divergent region and hipcc has no phi copies
+// to make at its end (they were 11 v_mov per sphere test).
 template <bool C, class V>
-__device__ __forceinline__ void intersect_shape(V& v, const RT_CONST rtx_shape& sh, uint32_t s, V4 o, V4 d) {
+__device__ __forceinline__ void intersect_shape(V& v, const RT_CONST rtx_shape& sh, uint32_t s, V4 o, V4 d, bool active) {
     const bool n1_visible = !(sh.flags & RTX_SHAPE_N1_INVISIBLE);
     // r.transform(inverse), src/ray.zig:13-18 (all branches wave-uniform)
     auto to_object_space = [&](V4& ro, V4& rd) {
@@ -458,7 +461,9 @@ __device__ __forceinline__ void intersect_shape(V& v, const RT_CONST rtx_shape& 
     if (sh.type == RTX_PLANE) {  // src/plane.zig:13-28 — reads only the y row of the object-space ray,
         V4 ro, rd;               // so the transform sits inside the branch and its x / z rows fall away
         to_object_space(ro, rd);
-        if (!(fabsf(rd.y) < kEpsilon)) offer1(v, s, n1_visible, -ro.y / rd.y);
+        float t = NAN;
+        if (active && !(fabsf(rd.y) < kEpsilon)) t = -ro.y / rd.y;
+        offer1(v, s, n1_visible, t);
         return;
     }
     V4 ro, rd;
@@ -471,10 +476,13 @@ __device__ __forceinline__ void intersect_shape(V& v, const RT_CONST rtx_shape& 
         const float b = 2.0f * dot<C>(rd, sphere_to_ray);
         const float c = dot<C>(sphere_to_ray, sphere_to_ray) - 1.0f;
         const float discriminant = b * b - 4.0f * a * c;
-        if (discriminant >= 0.0f) {
+        float t0 = NAN, t1 = NAN;
+        if (active && discriminant >= 0.0f) {
             const float sq = sqrtf(discriminant);
-            offer2(v, s, n1_visible, (-b - sq) / (2.0f * a), (-b + sq) / (2.0f * a));
+            t0 = (-b - sq) / (2.0f * a);
+            t1 = (-b + sq) / (2.0f * a);
         }
+        offer2(v, s, n1_visible, t0, t1);
         return;
     }
     case RTX_CUBE: {  // src/cube.zig:11-26
@@ -483,14 +491,14 @@ __device__ __forceinline__ void intersect_shape(V& v, const RT_CONST rtx_shape& 
         const TMinMax z = check_axis(-1.0f, 1.0f, ro.z, rd.z);
         const float tmin = fmaxf(x.tmin, fmaxf(y.tmin, z.tmin));
         const float tmax = fminf(x.tmax, fminf(y.tmax, z.tmax));
-        if (!(tmin > tmax)) offer2(v, s, n1_visible, tmin, tmax);
+        const bool crosses = active && !(tmin > tmax);
+        offer2(v, s, n1_visible, crosses ? tmin : NAN, crosses ? tmax : NAN);
         return;
     }
     case RTX_CYLINDER:  // src/cylinder.zig:14-71
     case RTX_CONE: {    // src/cone.zig:14-82
         const bool cone = sh.type == RTX_CONE;
-        float t[4];
-        bool ok[4] = {false, false, false, false};
+        float t[4] = {NAN, NAN, NAN, NAN};
         float a, b, c;
         if (cone) {
             a = rd.x * rd.x - rd.y * rd.y + rd.z * rd.z;
@@ -501,13 +509,10 @@ __device__ __forceinline__ void intersect_shape(V& v, const RT_CONST rtx_shape& 
             b = 2.0f * ro.x * rd.x + 2.0f * ro.z * rd.z;
             c = ro.x * ro.x + ro.z * ro.z - 1.0f;
         }
-        bool walls = true;
+        bool walls = active;
         if (approx_zero(a)) {
             walls = false;
-            if (cone && !approx_zero(b)) {  // src/cone.zig:35-39: the single root
-                t[0] = -c / (2.0f * b);
-                ok[0] = true;
-            }
+            if (active && cone && !approx_zero(b)) t[0] = -c / (2.0f * b);  // src/cone.zig:35-39: the single root
         }
         if (walls) {
             const float discriminant = b * b - 4.0f * a * c;
@@ -521,41 +526,29 @@ __device__ __forceinline__ void intersect_shape(V& v, const RT_CONST rtx_shape& 
                     t1 = tmp;
                 }
                 const float y0 = fmaf(t0, rd.y, ro.y);  // @mulAdd, cylinder.zig:40 / cone.zig:53
-                if (sh.minimum < y0 && y0 < sh.maximum) {
-                    t[0] = t0;
-                    ok[0] = true;
-                }
+                if (sh.minimum < y0 && y0 < sh.maximum) t[0] = t0;
                 const float y1 = fmaf(t1, rd.y, ro.y);  // @mulAdd, cylinder.zig:45 / cone.zig:58
-                if (sh.minimum < y1 && y1 < sh.maximum) {
-                    t[1] = t1;
-                    ok[1] = true;
-                }
+                if (sh.minimum < y1 && y1 < sh.maximum) t[1] = t1;
             }
         }
         // intersectCaps (src/cylinder.zig:53-71, src/cone.zig:66-82)
-        if ((sh.flags & RTX_SHAPE_CLOSED) && !approx_zero(rd.y)) {
+        if (active && (sh.flags & RTX_SHAPE_CLOSED) && !approx_zero(rd.y)) {
             const float t_lower = (sh.minimum - ro.y) / rd.y;
             {
                 const float x = fmaf(t_lower, rd.x, ro.x);  // checkCap, cylinder.zig:98-99 / cone.zig:111-112
                 const float z = fmaf(t_lower, rd.z, ro.z);
                 const float limit = cone ? fabsf(sh.minimum * sh.minimum) : 1.0f;
-                if ((x * x + z * z) <= limit) {
-                    t[2] = t_lower;
-                    ok[2] = true;
-                }
+                if ((x * x + z * z) <= limit) t[2] = t_lower;
             }
             const float t_upper = (sh.maximum - ro.y) / rd.y;
             {
                 const float x = fmaf(t_upper, rd.x, ro.x);
                 const float z = fmaf(t_upper, rd.z, ro.z);
                 const float limit = cone ? fabsf(sh.maximum * sh.maximum) : 1.0f;
-                if ((x * x + z * z) <= limit) {
-                    t[3] = t_upper;
-                    ok[3] = true;
-                }
+                if ((x * x + z * z) <= limit) t[3] = t_upper;
             }
         }
-        offer_roots(v, s, n1_visible, t, ok);
+        offer_roots(v, s, n1_visible, t);
         return;
     }
     default: {  // RTX_TRIANGLE
@@ -566,8 +559,9 @@ __device__ __forceinline__ void intersect_shape(V& v, const RT_CONST rtx_shape& 
             e0[k] = sh.e0[k];
             e1[k] = sh.e1[k];
         }
-        float tt;
-        if (triangle_root(ro, rd, p0, e0, e1, tt)) offer1(v, s, n1_visible, tt);
+        float root, tt = NAN;
+        if (active && triangle_root(ro, rd, p0, e0, e1, root)) tt = root;
+        offer1(v, s, n1_visible, tt);
         return;
     }
     }
@@ -665,9 +659,7 @@ __device__ __forceinline__ void traverse(V& v, const Params& p, V4 o, V4 d, bool
         const uint32_t bvh_root = BVH ? node.reserved[0] : 0u;  // root + 1, 0 = no BVH
         const uint32_t first = node.first_shape;
         const uint32_t last = first + (bvh_root ? node.reserved[1] : node.n_shapes);
-        for (uint32_t s = first; s < last; ++s) {
-            if (active) intersect_shape<C>(v, shapes[s], s, o, d);
-        }
+        for (uint32_t s = first; s < last; ++s) intersect_shape<C>(v, shapes[s], s, o, d, active);
         if (BVH && bvh_root && active) traverse_bvh<C>(v, p, bvh_root - 1u, o, d);
     }
 }
