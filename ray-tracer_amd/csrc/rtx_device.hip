@@ -267,9 +267,9 @@ template <bool TRACK>
 struct ClosestVisitor {
     Closest c;
     RTX_HD void init() {
-        c.t = 0.0f;
+        c.t = INFINITY;  // "none yet" carries the range end the BVH walk culls against (t_hi / t_lo)
         c.idx = kNone;
-        c.pred_t = 0.0f;
+        c.pred_t = -INFINITY;
         c.pred_idx = kNone;
     }
     // Ties go to the lowest insertion index for the hit and to the highest for the predecessor.
@@ -302,7 +302,7 @@ struct ClosestVisitor {
     RTX_HD bool done() const { return false; }
     // Range of t a BVH subtree must overlap to matter: [0, current best].
     RTX_HD float t_lo() const { return 0.0f; }
-    RTX_HD float t_hi() const { return c.idx == kNone ? INFINITY : c.t; }
+    RTX_HD float t_hi() const { return c.t; }
 };
 
 // The n1 predecessor among BVH triangles: the largest t < 0, ties to the highest insertion
@@ -322,7 +322,7 @@ struct PredVisitor {
     RTX_HD void visited_node() {}
     RTX_HD void tested_triangle() {}
     RTX_HD bool done() const { return false; }
-    RTX_HD float t_lo() const { return pred_idx == kNone ? -INFINITY : pred_t; }
+    RTX_HD float t_lo() const { return pred_t; }  // -inf while there is none (ClosestVisitor::init)
     RTX_HD float t_hi() const { return 0.0f; }
 };
 
@@ -2137,11 +2137,11 @@ int rtx_bvh_selftest(const rtx_scene_desc* desc, const float* origins, const flo
             traverse_bvh<false>(cv, p, root, o, d);
             g_selftest_nodes += cv.nodes;
             g_selftest_tris += cv.tris;
-            PredVisitor pv{0.0f, kNone};
+            PredVisitor pv{-INFINITY, kNone};
             traverse_bvh<false>(pv, p, root, o, d);
             ClosestVisitor<true> ref;
             ref.init();
-            PredVisitor pref{0.0f, kNone};
+            PredVisitor pref{-INFINITY, kNone};
             for (uint32_t t = first_tri; t < last_tri; ++t) {
                 const rtx_shape& sh = shapes[t];
                 V4 ro = o, rd = d;
