@@ -765,8 +765,13 @@ __device__ __forceinline__ V4 normal_at(const rtx_shape& sh, V4 world_point) {
     return normalize<C>(world_normal);
 }
 
-// @mod(x, 2) == 0 under floored modulo  <=>  fmodf(x, 2) is +-0.
-__device__ __forceinline__ bool mod2_is_zero(float x) { return fmodf(x, 2.0f) == 0.0f; }
+// @mod(x, 2) == 0 for the integer-valued x the patterns pass (a floor, or a sum of floors): x is even
+// <=> x / 2 is an integer; halving is exact, every float from 2^24 up is an even integer, NaN compares
+// false and an infinity (whose @mod is NaN) is excluded.  4 instructions; fmodf(x, 2) == 0 was ~30.
+__device__ __forceinline__ bool mod2_is_zero(float x) {
+    const float h = x * 0.5f;
+    return h == truncf(h) && fabsf(x) < INFINITY;
+}
 
 struct Color {
     float r, g, b;
