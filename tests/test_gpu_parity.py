@@ -224,6 +224,28 @@ def test_device_canvas_and_u8_quantisation():
     scene.close()
 
 
+@pytest.mark.parametrize("name,w,h", [("glass_spheres", 250, 127), ("striped_scene", 131, 70)])
+def test_u8_canvas_covers_every_pixel(name, w, h):
+    """f32 and u8 device canvases of one call: every pixel gets its bytes — ragged width (tile
+    padding), rows the 8-row quirk leaves black (src/camera.zig:87-88), multi-level pixels —
+    whatever the buffers held before, and whatever the batch size."""
+    import torch
+
+    s = rta.Sample(name, w, h)
+    scene = rta.Scene(s.world)
+    host, _ = scene.render(s.camera)
+    want = rta.to_ppm_bytes(host)
+    assert (want[8 * (h // 8):] == 0).all() and want.any()
+    for batch in (0, 16 * w):
+        rgb = torch.full((h, w, 3), 7.0, dtype=torch.float32, device="cuda")
+        rgb8 = torch.full((h, w, 3), 255, dtype=torch.uint8, device="cuda")
+        scene.render_device(s.camera, rgb.data_ptr(), rgb8.data_ptr(), batch_pixels=batch)
+        torch.cuda.synchronize()
+        assert rgb.cpu().numpy().tobytes() == host.tobytes()
+        assert np.array_equal(rgb8.cpu().numpy(), want)
+    scene.close()
+
+
 def test_frames_without_statistics_leave_the_counters_right_for_the_next_frame():
     """Frames that do not ask for statistics skip the totals kernel and rely on the alternating
     counter sets; a frame with statistics after any number of them must still count right, for
