@@ -1328,12 +1328,22 @@ __global__ void k_accumulate(Counters* c, Totals* t, uint32_t level0_rays, uint3
 }
 
 // canvas.zig:45-47: round(clamp(c * 255, 0, 255)), round half away from zero.
-__global__ void k_quantise(const float* rgb, uint8_t* out, size_t n) {
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        float v = rgb[i] * 255.0f;
-        v = fmaxf(0.0f, fminf(v, 255.0f));
-        out[i] = static_cast<uint8_t>(roundf(v));
+__device__ __forceinline__ uint32_t quantise(float c) {
+    float v = c * 255.0f;
+    v = fmaxf(0.0f, fminf(v, 255.0f));
+    return static_cast<uint32_t>(roundf(v));
+}
+// Four values per thread (one 16-byte load, one 4-byte store) where the buffers are aligned for it
+// (`n4` groups, 0 if they are not), one value per thread for the rest.
+__global__ void k_quantise(const float* rgb, uint8_t* out, size_t n, size_t n4) {
+    const size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    const float4* rgb4 = reinterpret_cast<const float4*>(rgb);
+    uint32_t* out4 = reinterpret_cast<uint32_t*>(out);
+    for (size_t i = tid; i < n4; i += stride) {
+        const float4 v = rgb4[i];
+        out4[i] = quantise(v.x) | (quantise(v.y) << 8) | (quantise(v.z) << 16) | (quantise(v.w) << 24);
     }
+    for (size_t i = 4 * n4 + tid; i < n; i += stride) out[i] = static_cast<uint8_t>(quantise(rgb[i]));
 }
 
 }  // namespace
@@ -1837,7 +1847,8 @@ int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_opts* opts, float
     }
     if (d_rgb8) {
         const size_t n = out_rows * W * 3;
-        hipLaunchKernelGGL(k_quantise, dim3(2048), dim3(256), 0, st, d_rgb, d_rgb8, n);
+        const bool aligned = (reinterpret_cast<uintptr_t>(d_rgb) % 16u == 0u) && (reinterpret_cast<uintptr_t>(d_rgb8) % 4u == 0u);
+        hipLaunchKernelGGL(k_quantise, dim3(2048), dim3(256), 0, st, d_rgb, d_rgb8, n, aligned ? n / 4 : (size_t)0);
     }
     HIP_TRY(hipEventRecord(s->ev_end, st));
     HIP_TRY(hipGetLastError());
