@@ -100,7 +100,8 @@ struct ShardCounters {  // one 128-byte line per shard
     unsigned long long hit_kinds;  // low 32: hits on patterned materials, high 32: on transparent ones
     uint32_t hits[kLevels];        // hits at level d == isShadowed calls
     uint32_t refr[kLevels];        // per level d: refracted rays queued for level d + 1 (their own region)
-    uint32_t pad[32 - 2 * kLevels - 2 - kLevels - kLevels];
+    uint32_t claim[kLevels];       // per level d: 64-ray chunks of this shard's level-d work handed out so far
+    static_assert(32 - 2 * kLevels - 2 - kLevels - kLevels == kLevels, "the claim words fill the line exactly");
 };
 static_assert(sizeof(ShardCounters) == 128, "one cache line per shard");
 
@@ -1045,7 +1046,19 @@ __attribute__((amdgpu_waves_per_eu((BVH || !C) ? RTX_WAVES_PER_EU : RTX_WAVES_PE
 
     uint32_t local_hits = 0, local_patterned = 0, local_transparent = 0;
     DIAG_DECL
-    for (uint32_t base = first; base < count; base += stride) {
+    // Chunks of 64 rays are handed out on demand — one returning atomic on the shard's line per
+    // iteration — instead of dealt in advance (wave w: chunks w, w + n_waves, ...): with the static
+    // deal a wave whose tiles cover the expensive part of the image finishes long after the others
+    // and the launch ends with most CUs idle.
+    auto next_base = [&]() -> uint32_t {
+        uint32_t k = 0u;
+        if (lane == 0u) k = atomicAdd(&sc->claim[level], 1u);
+        k = __shfl(k, 0);
+        return root ? (k * kShards + shard) * 64u : k * 64u;  // level 0: chunk c belongs to shard c % kShards
+    };
+    (void)first;
+    (void)stride;
+    for (uint32_t base = next_base(); base < count; base = next_base()) {
         DIAG_START();
         const uint32_t i = base + lane;
         bool on = i < count;
@@ -1302,6 +1315,7 @@ __global__ void k_accumulate(Counters* c, Totals* t, uint32_t level0_rays, uint3
         sc->alloc[l] = 0ull;
         sc->hits[l] = 0u;
         sc->refr[l] = 0u;
+        sc->claim[l] = 0u;
     }
     patterned = static_cast<uint32_t>(sc->hit_kinds);
     transparent = sc->hit_kinds >> 32;
