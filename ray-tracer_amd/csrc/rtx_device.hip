@@ -1014,27 +1014,22 @@ __attribute__((amdgpu_waves_per_eu((BVH || !C) ? RTX_WAVES_PER_EU : RTX_WAVES_PE
     const uint32_t qi = level & 1u, qo = qi ^ 1u;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;  // a multiple of kShards (host guarantees)
     const uint32_t shard = wave % kShards;
     ShardCounters* sc = &p.counters->shard[shard];
 
-    // Level 0 walks all items (wave w takes chunks w, w + n_waves, ...; chunk c belongs to
-    // shard c % kShards); deeper levels walk this wave's shard.
-    // Deeper levels: the shard's region holds reflected rays [0, n_refl_in) from its bottom and
-    // refracted rays from its top down; chunks of 64 cover first the one, then the other.
-    uint32_t count, first, stride, in_base, n_refl_in = 0u, n_refr_in = 0u, refl_span = 0u, in_top = 0u;
+    // Level 0 covers all items in chunks of 64, chunk c belonging to shard c % kShards; deeper
+    // levels cover this wave's shard: its region holds reflected rays [0, n_refl_in) from its
+    // bottom and refracted rays from its top down, and chunks of 64 cover first the one, then
+    // the other.  `count` is the end of the item range the waves of this shard claim chunks from.
+    uint32_t count, in_base, n_refl_in = 0u, n_refr_in = 0u, refl_span = 0u, in_top = 0u;
     if (root) {
         count = GEN ? p.tiles_x * ((p.n_rows + 7u) / 8u) * 64u : p.root_count;
-        first = wave * 64u;
-        stride = n_waves * 64u;
         in_base = 0u;
     } else {
         n_refl_in = static_cast<uint32_t>(sc->alloc[level - 1]);
         n_refr_in = sc->refr[level - 1];
         refl_span = (n_refl_in + 63u) & ~63u;
         count = refl_span + ((n_refr_in + 63u) & ~63u);
-        first = (wave / kShards) * 64u;
-        stride = (n_waves / kShards) * 64u;
         const uint32_t cap_in = p.shard_cap0 << (level * p.level_shift);
         in_base = shard * cap_in;
         in_top = in_base + cap_in - 1u;
@@ -1056,8 +1051,6 @@ __attribute__((amdgpu_waves_per_eu((BVH || !C) ? RTX_WAVES_PER_EU : RTX_WAVES_PE
         k = __shfl(k, 0);
         return root ? (k * kShards + shard) * 64u : k * 64u;  // level 0: chunk c belongs to shard c % kShards
     };
-    (void)first;
-    (void)stride;
     for (uint32_t base = next_base(); base < count; base = next_base()) {
         DIAG_START();
         const uint32_t i = base + lane;
