@@ -92,7 +92,11 @@ __device__ __forceinline__ const RT_CONST T* as_const(const T* p) {
 // rays and appends its children to the same shard.  A single counter word saturates near
 // 88 returning atomics per microsecond on MI355X (MI355X_MICROARCH.md, row "dequeue"), which
 // made the unsharded version 93 % SQ_WAIT_ANY (profiles/r01_*).
-constexpr uint32_t kShards = 64;
+#ifndef RTX_SHARDS
+#define RTX_SHARDS 64
+#endif
+constexpr uint32_t kShards = RTX_SHARDS;  // a multiple of 64, at most 256 (level 0's first block clears one line per thread)
+static_assert(kShards % 64u == 0u && kShards <= 256u, "see k_trace_shade and k_accumulate");
 
 struct ShardCounters {  // one 128-byte line per shard
     // per level d: low 32 bits = reflected rays queued for level d + 1, high 32 bits = interior nodes at d
@@ -1296,23 +1300,25 @@ __global__ __launch_bounds__(256) void k_combine(const Params p, const uint32_t 
 // Fold this batch's counters into the running totals and clear them for the next batch:
 // one wave, lane k owns shard k.  `reset` starts a new frame's totals.
 __global__ void k_accumulate(Counters* c, Totals* t, uint32_t level0_rays, uint32_t depth, uint32_t reset) {
-    const uint32_t k = threadIdx.x;  // blockDim.x == kShards == 64
-    ShardCounters* sc = &c->shard[k];
-    unsigned long long rays[kLevels], hits[kLevels], nodes = 0, patterned, transparent;
+    const uint32_t k = threadIdx.x;  // one wave; lane k owns shards k, k + 64, ...
+    unsigned long long rays[kLevels] = {}, hits[kLevels] = {}, nodes = 0, patterned = 0, transparent = 0;
+    for (uint32_t sh = k; sh < kShards; sh += 64u) {
+        ShardCounters* sc = &c->shard[sh];
 #pragma unroll
-    for (int l = 0; l < kLevels; ++l) {
-        const unsigned long long a = sc->alloc[l];
-        rays[l] = (static_cast<uint32_t>(l) <= depth) ? static_cast<unsigned long long>(static_cast<uint32_t>(a)) + sc->refr[l] : 0ull;
-        nodes += (static_cast<uint32_t>(l) <= depth) ? (a >> 32) : 0ull;
-        hits[l] = sc->hits[l];
-        sc->alloc[l] = 0ull;
-        sc->hits[l] = 0u;
-        sc->refr[l] = 0u;
-        sc->claim[l] = 0u;
+        for (int l = 0; l < kLevels; ++l) {
+            const unsigned long long a = sc->alloc[l];
+            rays[l] += (static_cast<uint32_t>(l) <= depth) ? static_cast<unsigned long long>(static_cast<uint32_t>(a)) + sc->refr[l] : 0ull;
+            nodes += (static_cast<uint32_t>(l) <= depth) ? (a >> 32) : 0ull;
+            hits[l] += sc->hits[l];
+            sc->alloc[l] = 0ull;
+            sc->hits[l] = 0u;
+            sc->refr[l] = 0u;
+            sc->claim[l] = 0u;
+        }
+        patterned += static_cast<uint32_t>(sc->hit_kinds);
+        transparent += sc->hit_kinds >> 32;
+        sc->hit_kinds = 0ull;
     }
-    patterned = static_cast<uint32_t>(sc->hit_kinds);
-    transparent = sc->hit_kinds >> 32;
-    sc->hit_kinds = 0ull;
     for (int off = 32; off > 0; off >>= 1) {
 #pragma unroll
         for (int l = 0; l < kLevels; ++l) {
@@ -1740,7 +1746,7 @@ int run_levels(rtx_scene* s, WorkSet& w, Params& p, uint32_t pixels, uint32_t le
     }
     // Frame totals (ray counts by level, hit kinds) only when the caller reads them back.
     if (want_totals)
-        hipLaunchKernelGGL(k_accumulate, dim3(1), dim3(kShards), 0, st, p.counters, w.d_totals, level0_items ? pixels : 0u, last_level,
+        hipLaunchKernelGGL(k_accumulate, dim3(1), dim3(64), 0, st, p.counters, w.d_totals, level0_items ? pixels : 0u, last_level,
                            first ? 1u : 0u);
     HIP_TRY(hipGetLastError());
     w.counter_set ^= 1u;
