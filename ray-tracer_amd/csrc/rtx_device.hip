@@ -104,13 +104,21 @@ struct ShardCounters {  // one 128-byte line per shard
     unsigned long long hit_kinds;  // low 32: hits on patterned materials, high 32: on transparent ones
     uint32_t hits[kLevels];        // hits at level d == isShadowed calls
     uint32_t refr[kLevels];        // per level d: refracted rays queued for level d + 1 (their own region)
-    uint32_t claim[kLevels];       // per level d: 64-ray chunks of this shard's level-d work handed out so far
-    static_assert(32 - 2 * kLevels - 2 - kLevels - kLevels == kLevels, "the claim words fill the line exactly");
+    uint32_t pad[32 - 2 * kLevels - 2 - kLevels - kLevels];
 };
 static_assert(sizeof(ShardCounters) == 128, "one cache line per shard");
 
+// Chunk claims live on a line of their own: every wave of a shard hits them once per iteration, and on
+// the allocation line they would queue behind (and ahead of) the slot atomics.
+struct ClaimLine {
+    uint32_t claim[kLevels];  // per level d: 64-ray chunks of this shard's level-d work handed out so far
+    uint32_t pad[32 - kLevels];
+};
+static_assert(sizeof(ClaimLine) == 128, "one cache line per shard");
+
 struct Counters {
     ShardCounters shard[kShards];
+    ClaimLine claims[kShards];
 };
 
 struct Totals {
@@ -1009,8 +1017,10 @@ __attribute__((amdgpu_waves_per_eu((BVH || !C) ? RTX_WAVES_PER_EU : RTX_WAVES_PE
     // launch clears the other for the batch after it (everything that used that set finished
     // before this kernel started), so frames that do not ask for statistics need neither a fill
     // nor k_accumulate between batches.
-    if (root && blockIdx.x == 0 && threadIdx.x < kShards) {
-        uint4* line = reinterpret_cast<uint4*>(&p.counters_next->shard[threadIdx.x]);
+    static_assert(sizeof(Counters) == 2u * kShards * 128u && 2u * kShards <= 16u * 256u, "one thread of the first blocks per line");
+    if (root && blockIdx.x * 256u + threadIdx.x < 2u * kShards) {
+        // lines [0, kShards) are the shard counters, [kShards, 2 kShards) the claim lines (struct Counters)
+        uint4* line = reinterpret_cast<uint4*>(p.counters_next) + (size_t)(blockIdx.x * 256u + threadIdx.x) * (sizeof(ShardCounters) / sizeof(uint4));
 #pragma unroll
         for (int k = 0; k < (int)(sizeof(ShardCounters) / sizeof(uint4)); ++k) line[k] = make_uint4(0u, 0u, 0u, 0u);
     }
@@ -1051,7 +1061,7 @@ __attribute__((amdgpu_waves_per_eu((BVH || !C) ? RTX_WAVES_PER_EU : RTX_WAVES_PE
     // and the launch ends with most CUs idle.
     auto next_base = [&]() -> uint32_t {
         uint32_t k = 0u;
-        if (lane == 0u) k = atomicAdd(&sc->claim[level], 1u);
+        if (lane == 0u) k = atomicAdd(&p.counters->claims[shard].claim[level], 1u);
         k = __shfl(k, 0);
         return root ? (k * kShards + shard) * 64u : k * 64u;  // level 0: chunk c belongs to shard c % kShards
     };
@@ -1313,7 +1323,7 @@ __global__ void k_accumulate(Counters* c, Totals* t, uint32_t level0_rays, uint3
             sc->alloc[l] = 0ull;
             sc->hits[l] = 0u;
             sc->refr[l] = 0u;
-            sc->claim[l] = 0u;
+            c->claims[sh].claim[l] = 0u;
         }
         patterned += static_cast<uint32_t>(sc->hit_kinds);
         transparent += sc->hit_kinds >> 32;
