@@ -56,7 +56,7 @@ VALU_PEAK_TFLOPS = 39.3  # 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz, one flop pe
                          # separately, and an unpacked f32 VALU wave-instruction occupies its SIMD
                          # for 4 cycles whatever it does — measured on the box, 4.06-4.23 cycles at
                          # 6 waves per SIMD for mul/add, fma and cmp/cndmask alike
-                         # (tools/microbench/valu_rate.hip, profiles/r01_l_valu_rate.txt).  The spec's
+                         # (tools/microbench/valu_rate.hip, profiles/r01_m_valu_rate.txt).  The spec's
                          # 157.3 TFLOP/s is that rate x 2 (FMA) x 2 (v_pk_* packed pairs).
 VALU_PEAK_FMA_TFLOPS = 78.6     # same issue rate with every instruction an FMA (not reachable under the parity contract)
 VALU_PEAK_SPEC_TFLOPS = 157.3   # packed FMA, MI355X_MICROARCH.md "Peak FP32 (vector)"
@@ -297,7 +297,7 @@ def main():
                 "flops_per_launch": flops_per_launch, "avg_launch_ms": avg_ms, "launches": launches,
                 "share_of_step": (ms_trace / profiled_steps) / (dt / args.steps * 1e3) if dt > 0 and profiled_steps else None,
                 "note": "f32 VALU roofline (no MFMA: divergent per-lane scalar math); peak = unfused, unpacked f32 issue rate, "
-                        "39.3 T lane-ops/s (measured 38.7: profiles/r01_l_valu_rate.txt); frac_of_fma_peak / frac_of_spec_peak "
+                        "39.3 T lane-ops/s (measured 38.7: profiles/r01_m_valu_rate.txt); frac_of_fma_peak / frac_of_spec_peak "
                         "price the same achieved figure against 78.6 (all-FMA) and 157.3 (packed FMA, the spec number); "
                         "rank 0's launches of every %d-th timed step, bracketed by HIP events on the render stream; "
                         "traffic = HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE) from the committed PMC pass "
