@@ -9,7 +9,7 @@ import re, sys
 cur = {}
 rows = []
 for line in sys.stdin:
-    m = re.search(r"remark: +([A-Za-z ]+): +(\S+)", line)
+    m = re.search(r"remark: +([A-Za-z ]+?)(?: \[[^\]]*\])?: +(\S+)", line)
     if not m: continue
     k, v = m.group(1).strip(), m.group(2)
     if k == "Function Name":
@@ -21,5 +21,5 @@ for r in rows:
     m = re.search(r"k_trace_shadeI((?:Lb\dE)+)", n)
     names = ["GEN", "TRACK", "LDS", "C", "BVH", "X5", "X6"]
     tag = "trace " + " ".join(k + v for k, v in zip(names, re.findall(r"Lb(\d)E", m.group(1)))) if m else n[:40]
-    print("%-36s VGPR %3s  spill %3s  scratch %5s  occ %s  SGPR %s" % (tag, r.get("VGPRs"), r.get("VGPRs Spill"), r.get("ScratchSize"), r.get("Occupancy"), r.get("SGPRs")))
+    print("%-36s VGPR %3s  spill %3s  scratch %5s  occ %s  SGPR %s" % (tag, r.get("VGPRs"), r.get("VGPRs Spill"), r.get("ScratchSize"), r.get("Occupancy"), r.get("TotalSGPRs")))
 '
