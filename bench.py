@@ -12,12 +12,12 @@ metric = Mrays/s, a ray being one colorAtInternal or one isShadowed call (SURVEY
 N > 1 (launched by torch.distributed.run, one rank per GPU; every rank holds the scenes):
 * default, "scaling": "weak" — a step is a batch of N frame pairs, rank r renders pair r whole
   and every u8 canvas is gathered on rank 0 with one RCCL gather per step, overlapped with the
-  next step's rendering (two canvas buffers).  A configs[1] frame takes 0.5 ms on one GPU, below
-  the grain at which splitting it pays (launch floors bound the split at 4.9x on
+  next step's rendering (two canvas buffers).  A configs[1] frame takes 0.4 ms on one GPU, below
+  the grain at which splitting it pays (launch floors bound the split at 3.8x on
   8 GPUs), so frames, not strips, are the unit a node deals out at this size.
 * --split-frames, "scaling": "strong" — north_star's tile sharding: every frame is split into
   16-row strips, rank r renders the strips s with s % N == r, the strips are gathered and
-  re-interleaved on rank 0 (the tool for 4K/8K frames; bound 6.7x at 8K).
+  re-interleaved on rank 0 (the tool for 4K/8K frames; bound 6.2x at 8K).
 Time is the max over ranks between two barrier+synchronize pairs; all gathers are inside it.
 
 Also reported in the same JSON line: `roofline` for the dominant kernel (k_trace_shade:
