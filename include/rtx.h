@@ -168,8 +168,16 @@ typedef struct rtx_stats {
     uint32_t launches_trace_shade;
     uint32_t launches_combine;
     uint32_t rows_rendered;
-    uint32_t reserved;
+    uint32_t kernel_flags;   /* RTX_KERNEL_*: the k_trace_shade variant this frame's level kernels were */
 } rtx_stats;
+
+/* rtx_stats.kernel_flags: template flags of the trace+shade kernel a frame dispatched. */
+enum {
+    RTX_KERNEL_CANONICAL_W = 1u << 0, /* w lanes left out (every point w == 1, every vector w == 0 exactly) */
+    RTX_KERNEL_BVH         = 1u << 1, /* some gate's triangle run is walked through its BVH */
+    RTX_KERNEL_LDS_TABLES  = 1u << 2, /* per-lane scene tables staged in LDS */
+    RTX_KERNEL_TRACK_N1    = 1u << 3  /* n1 predecessor tracked (some material is transparent) */
+};
 
 typedef struct rtx_scene rtx_scene; /* opaque; owns the device copies */
 

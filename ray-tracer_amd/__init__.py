@@ -76,7 +76,9 @@ class RtxStats(C.Structure):
                 ("level_rays", C.c_uint64 * 6), ("nodes", C.c_uint64),
                 ("level_hits", C.c_uint64 * 6), ("hits_patterned", C.c_uint64), ("hits_transparent", C.c_uint64),
                 ("ms_total", f32), ("ms_trace_shade", f32), ("ms_combine", f32),
-                ("launches_trace_shade", u32), ("launches_combine", u32), ("rows_rendered", u32), ("reserved", u32)]
+                ("launches_trace_shade", u32), ("launches_combine", u32), ("rows_rendered", u32), ("kernel_flags", u32)]
+
+    KERNEL_CANONICAL_W, KERNEL_BVH, KERNEL_LDS_TABLES, KERNEL_TRACK_N1 = 1, 2, 4, 8  # rtx.h RTX_KERNEL_*
 
     @property
     def rays_total(self):
@@ -229,6 +231,22 @@ class ObjFile:
         if getattr(self, "handle", None):
             lib().rt_obj_free(self.handle)
             self.handle = None
+
+
+def teapot_obj_text(level=1):
+    """OBJ text of the generated teapot (samples/make_teapot_obj.py), tessellation `level` (1 = the
+    committed samples/teapot.obj).  Generated in this process: nothing is spawned, so it is safe
+    under rocprofv3, whose preloaded library has initialised the GPU before Python starts."""
+    root = os.path.dirname(HERE)
+    if level == 1:
+        with open(os.path.join(root, "samples", "teapot.obj")) as f:
+            return f.read()
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("make_teapot_obj", os.path.join(root, "samples", "make_teapot_obj.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.obj_text(level)
 
 
 def teapot_scene(obj_text, width=256, height=256, extra=None):

@@ -1454,20 +1454,39 @@ void free_work(WorkSet* w) {
 // If some material is both, level d holds at most 2^d * pixels rays and as many interior
 // nodes; otherwise a level never outgrows the pixels.  Queue 0 carries the even levels and
 // queue 1 the odd ones.  `need_link`: the general-w ray format keeps link/weight in a third array.
+// Items per shard at level 0 for a batch of `pixels`, and the ray-tree nodes / queue slots a batch of
+// that size can need in the worst case (64-bit: the caller checks them against the 30-bit link index).
+struct WorkSizes {
+    uint32_t shard_cap0;
+    uint64_t per_level0, q_cap[2], node_cap;
+};
+WorkSizes work_sizes(uint64_t pixels, bool two_children) {
+    WorkSizes z;
+    // Level-0 chunks of 64 items are dealt round-robin to the shards, so a shard sees at most
+    // 64 * ceil(chunks / kShards) items at level 0 and (1 << shift * d) times that at level d.
+    const uint32_t shift = two_children ? 1u : 0u;
+    const uint64_t chunks = (pixels + 63u) / 64u;
+    z.shard_cap0 = (uint32_t)(64u * ((chunks + kShards - 1u) / kShards));
+    z.per_level0 = (uint64_t)kShards * z.shard_cap0;
+    z.q_cap[0] = z.per_level0 << (shift * (kMaxDepth - 1));  // levels 0, 2, 4
+    z.q_cap[1] = z.per_level0 << (shift * kMaxDepth);        // levels 1, 3, 5
+    z.node_cap = 0;
+    for (int l = 0; l < kMaxDepth; ++l) z.node_cap += z.per_level0 << (shift * l);
+    return z;
+}
+
 int ensure_work(const rtx_scene* s, WorkSet* w, uint32_t pixels, bool need_link) {
     if (pixels <= w->cap_pixels && (!need_link || w->q_link[0])) return RTX_OK;
     if (pixels < w->cap_pixels) pixels = w->cap_pixels;
     need_link = need_link || w->q_link[0];
     free_work(w);
-    // Level-0 chunks of 64 items are dealt round-robin to the shards, so a shard sees at most
-    // 64 * ceil(chunks / kShards) items at level 0 and (1 << shift * d) times that at level d.
-    const uint32_t shift = s->two_children ? 1u : 0u;
-    const uint32_t chunks = (pixels + 63u) / 64u;
-    const uint32_t shard_cap0 = 64u * ((chunks + kShards - 1u) / kShards);
-    const size_t per_level0 = (size_t)kShards * shard_cap0;
-    const size_t q_cap[2] = {per_level0 << (shift * (kMaxDepth - 1)), per_level0 << (shift * kMaxDepth)};  // levels 4 and 5
-    size_t node_cap = 0;
-    for (int l = 0; l < kMaxDepth; ++l) node_cap += per_level0 << (shift * l);
+    const WorkSizes z = work_sizes(pixels, s->two_children);
+    if (z.node_cap > kLinkIndexMask || z.q_cap[1] > 0xFFFFFFFFull)
+        return fail(RTX_E_INVALID, "a batch of %u pixels needs %llu ray-tree nodes: beyond the 30-bit node index", pixels,
+                    (unsigned long long)z.node_cap);
+    const uint32_t shard_cap0 = z.shard_cap0;
+    const size_t q_cap[2] = {(size_t)z.q_cap[0], (size_t)z.q_cap[1]};
+    const size_t node_cap = (size_t)z.node_cap;
     for (int i = 0; i < 2; ++i) {
         HIP_TRY(hipMalloc(&w->q_org[i], q_cap[i] * sizeof(float4)));
         HIP_TRY(hipMalloc(&w->q_dir[i], q_cap[i] * sizeof(float4)));
@@ -1623,9 +1642,11 @@ void build_bvhs(std::vector<rtx_shape>& shapes, std::vector<rtx_node>& nodes, st
     for (rtx_node& n : nodes) n.reserved[0] = n.reserved[1] = 0;
     linear = nodes;
     for (rtx_node& n : nodes) {
-        // shapes of a node are in type order, so its triangles are the tail of its range
-        uint32_t n_lin = 0;
-        while (n_lin < n.n_shapes && shapes[n.first_shape + n_lin].type != RTX_TRIANGLE) ++n_lin;
+        // rt_flatten emits a node's shapes in type order, so its triangles are the tail of its range.
+        // The ABI does not require that order: only the maximal trailing run of triangles goes into
+        // the tree, whatever precedes it (triangles included) is tested linearly, in insertion order.
+        uint32_t n_lin = n.n_shapes;
+        while (n_lin > 0 && shapes[n.first_shape + n_lin - 1].type == RTX_TRIANGLE) --n_lin;
         const uint32_t n_tri = n.n_shapes - n_lin;
         if (n_tri < rtx_bvh::kMinTris) continue;
         const uint32_t root = rtx_bvh::build_run(shapes.data(), n.first_shape + n_lin, n_tri, bvh_nodes, bvh_tris);
@@ -1670,7 +1691,7 @@ void fill_scene_params(const rtx_scene* s, Params& p, uint32_t depth) {
 
 // Sum the pending profile events into `out` and mark them consumed (stream must be idle).
 int collect_profile(rtx_scene* s, rtx_stats* out) {
-    for (size_t i = 0; i + 1 < s->prof_used; i += 2) {
+    for (size_t i = 0; i + 1 < s->prof_used && i / 2 < s->prof_kind.size(); i += 2) {
         float ms = 0.0f;
         HIP_TRY(hipEventElapsedTime(&ms, s->prof_events[i], s->prof_events[i + 1]));
         if (s->prof_kind[i / 2] == 0) {
@@ -1727,15 +1748,34 @@ int run_levels(rtx_scene* s, WorkSet& w, Params& p, uint32_t pixels, uint32_t le
         if (blocks < kBlockQuantum) blocks = kBlockQuantum;
         return (uint32_t)blocks;
     };
+    // Events come in (begin, end) pairs, prof_kind holds one entry per pair.  If an event cannot be
+    // created or recorded, profiling stops for the rest of this call and the half-recorded pair is
+    // dropped, so collect_profile never pairs events of different launches.
     auto mark = [&](int kind) {
         if (!prof) return;
+        const bool begin = kind >= 0;
         if (s->prof_used == s->prof_events.size()) {
             hipEvent_t e;
-            if (hipEventCreateWithFlags(&e, hipEventReleaseToDevice) != hipSuccess) return;  // device-scope release: no system-wide flush around the timed launch
+            if (hipEventCreateWithFlags(&e, hipEventReleaseToDevice) != hipSuccess) {  // device-scope release: no system-wide flush around the timed launch
+                prof = false;
+                if (!begin) {  // the pair's begin event is already in: take it out again
+                    --s->prof_used;
+                    s->prof_kind.pop_back();
+                }
+                return;
+            }
             s->prof_events.push_back(e);
         }
-        (void)hipEventRecord(s->prof_events[s->prof_used++], st);
-        if (kind >= 0) s->prof_kind.push_back(kind);
+        if (hipEventRecord(s->prof_events[s->prof_used], st) != hipSuccess) {
+            prof = false;
+            if (!begin) {
+                --s->prof_used;
+                s->prof_kind.pop_back();
+            }
+            return;
+        }
+        ++s->prof_used;
+        if (begin) s->prof_kind.push_back(kind);
     };
     // A scene without a reflective or transparent material never spawns a child ray
     // (src/world.zig:131,151): its deeper levels would be empty launches.
@@ -1809,6 +1849,13 @@ int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_opts* opts, float
         if (half < rows_per_batch) rows_per_batch = half;
     }
     const uint32_t tiles_x = (W + 7u) / 8u;
+    // The clamp on batch_pixels alone does not bound the node index: tile padding (W = 1 pads to 8) and
+    // the rounding of shard capacities add to it.  Shrink the batch until the worst-case node count
+    // fits the 30-bit link index (a batch is at least one 8-row band).
+    while (rows_per_batch > 8u && work_sizes((uint64_t)tiles_x * 8u * rows_per_batch, s->two_children).node_cap > kLinkIndexMask)
+        rows_per_batch = ((rows_per_batch / 2u) + 7u) & ~7u;
+    if (work_sizes((uint64_t)tiles_x * 8u * rows_per_batch, s->two_children).node_cap > kLinkIndexMask)
+        return fail(RTX_E_INVALID, "canvas too wide: one 8-row band of %u pixels exceeds the ray-tree node index", W);
     const uint32_t cap = tiles_x * 8u * rows_per_batch;  // pixels incl. tile padding
     Params p;
     fill_scene_params(s, p, depth);
@@ -1905,6 +1952,8 @@ int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_opts* opts, float
         stats->hits_patterned = t.hits_patterned;
         stats->hits_transparent = t.hits_transparent;
         stats->rows_rendered = plan.rows_local;
+        stats->kernel_flags = (p.canon ? RTX_KERNEL_CANONICAL_W : 0u) | (p.has_bvh ? RTX_KERNEL_BVH : 0u) |
+                              (p.lds_bytes ? RTX_KERNEL_LDS_TABLES : 0u) | (s->track_n1 ? RTX_KERNEL_TRACK_N1 : 0u);
         HIP_TRY(hipEventElapsedTime(&stats->ms_total, s->ev_begin, s->ev_end));
         if (profile) {
             rc = collect_profile(s, stats);
@@ -1998,7 +2047,11 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out) {
         const float* m = sh.inverse;
         if (!(m[12] == 0.0f && m[13] == 0.0f && m[14] == 0.0f && m[15] == 1.0f)) s->canon = false;
         if (sh.type == RTX_CUBE && !(m[3] == 0.0f && m[7] == 0.0f && m[11] == 0.0f)) s->canon = false;
-        if (sh.type == RTX_TRIANGLE && sh.normal[3] != 0.0f) s->canon = false;
+        // A triangle whose e0 is exactly zero (the OBJ fan's degenerate first triangle, src/obj_file.zig:156-164)
+        // has det == 0 (or NaN) for every ray and is never hit (src/triangle.zig:36-37): its normal —
+        // normalize(0) = NaN — is never read and does not decide anything here.
+        const bool never_hit = sh.type == RTX_TRIANGLE && sh.e0[0] == 0.0f && sh.e0[1] == 0.0f && sh.e0[2] == 0.0f && sh.e0[3] == 0.0f;
+        if (sh.type == RTX_TRIANGLE && !never_hit && !(sh.normal[3] == 0.0f)) s->canon = false;
     }
     std::vector<rtx_node> linear;
     std::vector<rtx_bvh::Node> bvh_nodes;

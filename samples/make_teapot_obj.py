@@ -114,6 +114,11 @@ def teapot(level=1):
     return mesh
 
 
+def obj_text(level=1):
+    """The OBJ text of the level-`level` tessellation (what this script prints)."""
+    return "\n".join(teapot(level).lines) + "\n"
+
+
 if __name__ == "__main__":
     level = int(sys.argv[1]) if len(sys.argv) > 1 else 1
     m = teapot(level)

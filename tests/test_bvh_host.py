@@ -4,7 +4,6 @@ No GPU involved; the GPU tests (test_gpu_parity.py) repeat the brute-force compa
 import ctypes as C
 import importlib
 import os
-import subprocess
 import sys
 
 import numpy as np
@@ -18,10 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def teapot_text(level=1):
-    if level == 1:
-        return open(os.path.join(ROOT, "samples", "teapot.obj")).read()
-    return subprocess.run([sys.executable, os.path.join(ROOT, "samples", "make_teapot_obj.py"), str(level)],
-                          capture_output=True, text=True, check=True).stdout
+    return rta.teapot_obj_text(level)
 
 
 def selftest(world, origins, dirs):
@@ -108,3 +104,36 @@ def test_short_triangle_runs_and_plain_scenes_get_no_bvh():
     assert selftest(s.world, np.zeros((0, 4)), np.zeros((0, 4)))[:2] == (0, 0)
     s = rta.Sample("glass_spheres")
     assert selftest(s.world, np.zeros((0, 4)), np.zeros((0, 4)))[:2] == (0, 0)
+
+
+def test_triangle_run_is_taken_from_the_tail_whatever_the_type_order():
+    """The C ABI does not require a node's shapes in type order (rt_flatten happens to emit them so).
+    Only the maximal trailing run of triangles may go into a BVH: with [triangles..., sphere] nothing
+    does (the sphere must not be swallowed as a triangle), with [triangle, sphere, triangles...] the tail does."""
+    world, cam, keep = rta.teapot_scene(teapot_text(), 64, 64)
+    flat = rta.FlatScene(world)
+    d = flat.desc
+    nodes = [d.nodes[i] for i in range(d.n_nodes)]
+    big = max(nodes, key=lambda n: n.n_shapes)
+    assert big.n_shapes >= 64
+    last = d.shapes[big.first_shape + big.n_shapes - 1]
+    saved = (last.type, list(last.inverse))
+    nn, nt, bad = C.c_uint32(), C.c_uint32(), C.c_uint32()
+
+    def run():
+        rc = rta.lib().rtx_bvh_selftest(C.byref(d), None, None, 0, C.byref(nn), C.byref(nt), C.byref(bad))
+        assert rc == 0, rta.lib().rtx_last_error()
+        return nn.value, nt.value
+
+    whole = run()
+    last.type = 0  # the node now ends in a sphere
+    others = sum(n.n_shapes for n in nodes if n is not big and n.n_shapes >= 16)
+    n_nodes, n_tris = run()
+    assert n_tris < whole[1] and n_tris <= others  # nothing of the big node went into a tree
+    last.type = saved[0]
+    mid = d.shapes[big.first_shape + 1]
+    mid.type = 0  # [triangle, sphere, triangles...]: the tail after the sphere is still a run
+    n_nodes, n_tris = run()
+    assert 0 < whole[1] - n_tris <= 2
+    mid.type = 5
+    assert run() == whole

@@ -294,13 +294,7 @@ ROOT = __import__("os").path.dirname(__import__("os").path.dirname(__import__("o
 
 
 def _teapot_text(level=1):
-    import subprocess
-    import sys
-
-    if level == 1:
-        return open(ROOT + "/samples/teapot.obj").read()
-    return subprocess.run([sys.executable, ROOT + "/samples/make_teapot_obj.py", str(level)], capture_output=True,
-                          text=True, check=True).stdout
+    return rta.teapot_obj_text(level)
 
 
 def test_teapot_matches_oracle_with_and_without_bvh():
@@ -311,10 +305,82 @@ def test_teapot_matches_oracle_with_and_without_bvh():
     compare(gpu, ref, "teapot (BVH)")
     lin, stats_lin = scene.render(cam, no_bvh=True)
     compare(lin, ref, "teapot (linear)")
-    full, _ = scene.render(cam, full_w=True)
+    full, stats_full = scene.render(cam, full_w=True)
     compare(full, ref, "teapot (BVH, full_w)")
     assert stats.rays_total == counts.total == stats_lin.rays_total
+    # The OBJ fan's degenerate triangles (NaN normals, never hit) must not push the frame off the
+    # canonical-w kernels: the three renders above are three different kernel variants.
+    K = rta.RtxStats
+    assert stats.kernel_flags & (K.KERNEL_CANONICAL_W | K.KERNEL_BVH) == K.KERNEL_CANONICAL_W | K.KERNEL_BVH
+    assert stats_lin.kernel_flags & (K.KERNEL_CANONICAL_W | K.KERNEL_BVH) == K.KERNEL_CANONICAL_W
+    assert stats_full.kernel_flags & (K.KERNEL_CANONICAL_W | K.KERNEL_BVH) == K.KERNEL_BVH
+    assert not stats.kernel_flags & K.KERNEL_LDS_TABLES  # 1568 shapes x 160 B do not fit the LDS budget
     scene.close()
+
+
+def _torus_obj(nu, nv, R=2.0, r=0.8):
+    """A torus of nu x nv quads around the y axis, centred at y = 1 (each quad becomes three fan
+    triangles, the first degenerate: src/obj_file.zig:156-164)."""
+    import math
+
+    lines = []
+    for i in range(nu):
+        for j in range(nv):
+            a, b = 2 * math.pi * i / nu, 2 * math.pi * j / nv
+            lines.append("v %.6f %.6f %.6f" % ((R + r * math.cos(b)) * math.cos(a), 1.0 + r * math.sin(b), (R + r * math.cos(b)) * math.sin(a)))
+    for i in range(nu):
+        for j in range(nv):
+            q = [i * nv + j, ((i + 1) % nu) * nv + j, ((i + 1) % nu) * nv + (j + 1) % nv, i * nv + (j + 1) % nv]
+            lines.append("f " + " ".join(str(k + 1) for k in q))
+    return "\n".join(lines) + "\n"
+
+
+@pytest.mark.parametrize("glass", [False, True])
+def test_small_mesh_runs_the_canonical_bvh_kernels_with_lds_tables(glass):
+    """A mesh small enough for the LDS-staged tables (<= 32 KB of records) and large enough for a BVH:
+    the <LDS, C, BVH> kernels, with and without n1 tracking, against the oracle and the other variants."""
+    extra = None
+    if glass:
+        g = rta.Sample("glass_spheres")
+        ball = g.world.spheres[0]
+        ball.common_attrs.transform = su.compose(su.translation(0.0, 1.2, -2.5), su.scaling(0.8, 0.8, 0.8))
+        extra = {"spheres": [ball]}
+    world, cam, keep = rta.teapot_scene(_torus_obj(8, 6), 96, 80, extra=extra)
+    ref, counts = o.render(cam, world)
+    scene = rta.Scene(world)
+    gpu, stats = scene.render(cam)
+    compare(gpu, ref, "torus mesh")
+    K = rta.RtxStats
+    want = K.KERNEL_CANONICAL_W | K.KERNEL_BVH | K.KERNEL_LDS_TABLES | (K.KERNEL_TRACK_N1 if glass else 0)
+    assert stats.kernel_flags == want, stats.kernel_flags
+    assert stats.rays_total == counts.total and stats.rays_shadow > 500
+    for kw in ({"full_w": True}, {"no_bvh": True}, {"full_w": True, "no_bvh": True}):
+        other, so = scene.render(cam, **kw)
+        compare(other, ref, "torus mesh %r" % kw)
+        assert so.rays_total == counts.total and so.kernel_flags != stats.kernel_flags
+    scene.close()
+
+
+def test_composite_at_3840x2160_north_star_target():
+    """The frame bench.py's headline is measured on (teapot + glass spheres + reflective floor, depth 5):
+    canonical-w BVH kernels, sampled rows against the oracle, the four-lane kernels and strips agree."""
+    world, cam, keep = rta.composite_scene(_teapot_text(), 3840, 2160)
+    scene = rta.Scene(world)
+    a, sa = scene.render(cam)
+    K = rta.RtxStats
+    assert sa.kernel_flags & (K.KERNEL_CANONICAL_W | K.KERNEL_BVH | K.KERNEL_TRACK_N1) == K.KERNEL_CANONICAL_W | K.KERNEL_BVH | K.KERNEL_TRACK_N1
+    assert sa.rays_primary == 3840 * 2160 and sa.rays_secondary > sa.rays_primary // 2
+    b, sb = scene.render(cam, full_w=True)
+    assert not sb.kernel_flags & K.KERNEL_CANONICAL_W
+    compare(b, a, "composite 3840x2160, canonical vs four-lane kernels")
+    assert sb.rays_total == sa.rays_total
+    part, sp = scene.render(cam, strips=(16, 8, 3), compact_rows=True)
+    ys = [y for y in range(2160) if (y // 16) % 8 == 3]
+    assert part.tobytes() == a[ys].tobytes()
+    scene.close()
+    ys = list(range(0, 2160, 270))  # the first row of each of the oracle's 8 bands: sky, teapot, spheres, floor reflections
+    ref, _ = o.render(cam, world, row_step=270)
+    compare(a[ys], ref[ys], "composite 3840x2160 sampled rows")
 
 
 def test_teapot_with_glass_and_mirror_matches_oracle():

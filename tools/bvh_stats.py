@@ -4,7 +4,6 @@ per camera ray of the teapot scene.    python tools/bvh_stats.py [level] [W H]""
 import ctypes as C
 import importlib
 import os
-import subprocess
 import sys
 
 import numpy as np
@@ -17,7 +16,7 @@ st = rta.st
 level = sys.argv[1] if len(sys.argv) > 1 else "1"
 w = int(sys.argv[2]) if len(sys.argv) > 2 else 192
 h = int(sys.argv[3]) if len(sys.argv) > 3 else 108
-text = subprocess.run([sys.executable, os.path.join(ROOT, "samples", "make_teapot_obj.py"), level], capture_output=True, text=True, check=True).stdout
+text = rta.teapot_obj_text(int(level))
 world, cam, keep = rta.teapot_scene(text, w, h)
 flat = rta.FlatScene(world)
 rays_o, rays_d = [], []

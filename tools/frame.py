@@ -18,11 +18,8 @@ frames = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 batch = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 no_bvh = os.environ.get("RTX_NO_BVH") == "1"
 if name.split(":")[0] in ("teapot", "composite"):
-    import subprocess
-
     level = name.split(":")[1] if ":" in name else "1"
-    text = subprocess.run([sys.executable, os.path.join(ROOT, "samples", "make_teapot_obj.py"), level],
-                          capture_output=True, text=True, check=True).stdout
+    text = rta.teapot_obj_text(int(level))  # in-process: nothing may be spawned under rocprofv3
     world, cam, keep = (rta.teapot_scene if name.startswith("teapot") else rta.composite_scene)(text, w, h)
 else:
     s = rta.Sample(name, w, h)

@@ -9,7 +9,6 @@ before the gather.  Scenes as in tools/frame.py (sample names, teapot:L, composi
 """
 import importlib
 import os
-import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -20,8 +19,7 @@ name, w, h, ranks = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.arg
 strip_rows = int(sys.argv[5]) if len(sys.argv) > 5 else 16
 if name.split(":")[0] in ("teapot", "composite"):
     level = name.split(":")[1] if ":" in name else "1"
-    text = subprocess.run([sys.executable, os.path.join(ROOT, "samples", "make_teapot_obj.py"), level],
-                          capture_output=True, text=True, check=True).stdout
+    text = rta.teapot_obj_text(int(level))
     world, cam, keep = (rta.teapot_scene if name.startswith("teapot") else rta.composite_scene)(text, w, h)
 else:
     s = rta.Sample(name, w, h)
