@@ -209,6 +209,24 @@ int rtx_render_device(rtx_scene* scene, const rtx_camera* cam, const rtx_opts* o
                       void* d_rgb8_out, void* stream, rtx_stats* stats);
 
 /*
+ * rtx_render_device for callers that cannot allocate — code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc.  No counterpart in the reference (whose render() allocates its
+ * canvas and its per-ray lists, src/camera.zig:84-105, src/world.zig:86).  Same arguments and the same
+ * canvas, bit for bit, as rtx_render_device without `stats`; the ray queues, ray-tree nodes and
+ * counters live in a file-scope device array of 29 MiB that every GPU the library is loaded on holds
+ * until the process ends, instead of in buffers grown with hipMalloc.  The call allocates and frees
+ * nothing, on the host or on the device, and does not synchronise.
+ * Limit: frames up to rtx_static_max_width() = 1024 pixels wide, any height (the frame is rendered in
+ * 8-row bands of at most 8192 pixels); a wider camera is rejected with RTX_E_INVALID.  opts->lanes and
+ * opts->profile are ignored (one stream, no per-launch events).
+ * Every call on a GPU — from any rtx_scene, any thread — shares that GPU's array: calls that overlap
+ * on one GPU race; calls ordered on one stream, or separated by a synchronisation, are fine.
+ */
+int rtx_render_device_static(rtx_scene* scene, const rtx_camera* cam, const rtx_opts* opts, void* d_rgb_out,
+                             void* d_rgb8_out, void* stream);
+uint32_t rtx_static_max_width(void);
+
+/*
  * With opts->profile = 1 every kernel launch is bracketed by HIP events on the render
  * stream.  A call that passes `stats` reads them back itself; calls that do not (the
  * asynchronous frame loop) leave them pending, and this collects everything recorded since

@@ -93,6 +93,8 @@ _SIGNATURES = [
     ("rtx_rows_for", C.c_int, [P(RtxCamera), P(RtxOpts), P(u32)]),
     ("rtx_render", C.c_int, [C.c_void_p, P(RtxCamera), P(RtxOpts), P(f32), P(RtxStats)]),
     ("rtx_render_device", C.c_int, [C.c_void_p, P(RtxCamera), P(RtxOpts), C.c_void_p, C.c_void_p, C.c_void_p, P(RtxStats)]),
+    ("rtx_render_device_static", C.c_int, [C.c_void_p, P(RtxCamera), P(RtxOpts), C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("rtx_static_max_width", u32, []),
     ("rtx_profile_collect", C.c_int, [C.c_void_p, P(RtxStats)]),
     ("rtx_color_at", C.c_int, [C.c_void_p, P(f32), P(f32), u32, u32, P(f32)]),
     ("rtx_bvh_selftest", C.c_int, [P(RtxSceneDesc), P(f32), P(f32), u32, P(u32), P(u32), P(u32)]),
@@ -353,6 +355,17 @@ class Scene:
                                    C.c_void_p(d_rgb8) if d_rgb8 else None, C.c_void_p(stream) if stream else None,
                                    C.byref(stats) if stats is not None else None))
         return stats
+
+    def render_device_static(self, cam, d_rgb, d_rgb8=None, stream=None, **kw):
+        """rtx_render_device_static: the same canvas through the never-allocated work set (width <= 1024)."""
+        rc = flatten_camera(cam) if isinstance(cam, st.Camera) else cam
+        opts = RtxOpts(depth=kw.get("depth", 0), rows_quirk=1 if kw.get("rows_quirk", True) else 0,
+                       batch_pixels=kw.get("batch_pixels", 0), compact_rows=1 if kw.get("compact_rows", False) else 0,
+                       no_bvh=1 if kw.get("no_bvh", False) else 0, full_w=1 if kw.get("full_w", False) else 0)
+        if kw.get("strips") is not None:
+            opts.strip_rows, opts.strip_count, opts.strip_index = kw["strips"]
+        _check(lib().rtx_render_device_static(self.handle, C.byref(rc), C.byref(opts), C.c_void_p(d_rgb),
+                                              C.c_void_p(d_rgb8) if d_rgb8 else None, C.c_void_p(stream) if stream else None))
 
     def profile_collect(self):
         """Sum the pending per-launch HIP-event timings (profile=True frames) -> RtxStats."""

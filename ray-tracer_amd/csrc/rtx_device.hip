@@ -29,6 +29,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -1394,6 +1395,39 @@ struct WorkSet {
     hipEvent_t done = nullptr;
 };
 
+// ---- work buffers that are never allocated: rtx_render_device_static --------------------------
+//
+// Callers that cannot call hipMalloc (HIP graph capture, tight serving loops, harnesses that forbid
+// it) render through one work set carved out of this file-scope device array.  It is sized for
+// batches of kStaticPixels pixels in the worst case (every hit spawns two children): frames up to
+// kStaticPixels / 8 pixels wide render in 8-row bands of that size.  Each GPU the library runs on
+// holds its own copy of the array, at its own address, from module load until the process ends.
+// In host code `scratch` is only a stand-in for the symbol: the address kernels and memsets use
+// comes from hipGetSymbolAddress, once per device (static_scratch_base).
+constexpr uint32_t kStaticPixels = 8192;
+constexpr uint32_t kStaticMaxWidth = kStaticPixels / 8u;
+constexpr size_t align256(size_t n) { return (n + 255u) & ~(size_t)255u; }
+constexpr size_t kStaticPerLevel0 = kStaticPixels;  // kShards * 64 * ceil(ceil(px / 64) / kShards) for px a multiple of 64 * kShards
+static_assert(kStaticPixels % (64u * kShards) == 0u, "kStaticPerLevel0 assumes whole chunk rounds");
+constexpr size_t kStaticQCap[2] = {kStaticPerLevel0 << (kMaxDepth - 1), kStaticPerLevel0 << kMaxDepth};
+constexpr size_t kStaticNodeCap = kStaticPerLevel0 * ((1u << kMaxDepth) - 1u);
+// layout: [counters x2][q_org0][q_org1][q_dir0][q_dir1][q_link0][q_link1][node_a][node_b][node_c][node_d]
+constexpr size_t kStaticOffCounters = 0;
+constexpr size_t kStaticOffQOrg0 = kStaticOffCounters + align256(2 * sizeof(Counters));
+constexpr size_t kStaticOffQOrg1 = kStaticOffQOrg0 + align256(kStaticQCap[0] * sizeof(float4));
+constexpr size_t kStaticOffQDir0 = kStaticOffQOrg1 + align256(kStaticQCap[1] * sizeof(float4));
+constexpr size_t kStaticOffQDir1 = kStaticOffQDir0 + align256(kStaticQCap[0] * sizeof(float4));
+constexpr size_t kStaticOffQLink0 = kStaticOffQDir1 + align256(kStaticQCap[1] * sizeof(float4));
+constexpr size_t kStaticOffQLink1 = kStaticOffQLink0 + align256(kStaticQCap[0] * sizeof(uint2));
+constexpr size_t kStaticOffNodeA = kStaticOffQLink1 + align256(kStaticQCap[1] * sizeof(uint2));
+constexpr size_t kStaticOffNodeB = kStaticOffNodeA + align256(kStaticNodeCap * sizeof(float4));
+constexpr size_t kStaticOffNodeC = kStaticOffNodeB + align256(kStaticNodeCap * sizeof(float4));
+constexpr size_t kStaticOffNodeD = kStaticOffNodeC + align256(kStaticNodeCap * sizeof(float4));
+constexpr size_t kStaticScratchBytes = kStaticOffNodeD + align256(kStaticNodeCap * sizeof(uint2));
+static_assert(kStaticScratchBytes <= (32u << 20), "the static work set is documented as at most 32 MiB per GPU");
+
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+
 struct rtx_scene {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -1418,6 +1452,7 @@ struct rtx_scene {
     // them on two streams, so the kernels of one batch fill the tails (and the empty deep
     // levels) of the other's.
     WorkSet ws[kLanes];
+    WorkSet ws_static;  // pointers into this device's `scratch` (rtx_render_device_static); owns nothing
     hipEvent_t ev_fork = nullptr;
     float* d_canvas = nullptr;  // staging canvas for the host-output entry points
     size_t canvas_floats = 0;
@@ -1431,6 +1466,49 @@ struct rtx_scene {
 };
 
 namespace {
+
+// Device address of `scratch` on `device`, which must be the current device: looked up with
+// hipGetSymbolAddress the first time the library is set up on that device (rtx_scene_create) and
+// kept — every GPU holds its own copy of the array at its own address.
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+unsigned char* g_scratch_ptr[kMaxDevices] = {};
+
+int static_scratch_base(int device, unsigned char** out) {
+    if (device < 0 || device >= kMaxDevices) return fail(RTX_E_INVALID, "device %d: the static work set supports devices 0..%d", device, kMaxDevices - 1);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void* ptr = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+        if (!ptr) return fail(RTX_E_HIP, "hipGetSymbolAddress(scratch) returned a null address on device %d", device);
+        g_scratch_ptr[device] = static_cast<unsigned char*>(ptr);
+    }
+    *out = g_scratch_ptr[device];
+    return RTX_OK;
+}
+
+// Point a work set at the static array of `device` (current).  Nothing is allocated or owned.
+int bind_static_work(int device, WorkSet* w) {
+    unsigned char* base = nullptr;
+    const int rc = static_scratch_base(device, &base);
+    if (rc) return rc;
+    w->d_counters = reinterpret_cast<Counters*>(base + kStaticOffCounters);
+    w->q_org[0] = reinterpret_cast<float4*>(base + kStaticOffQOrg0);
+    w->q_org[1] = reinterpret_cast<float4*>(base + kStaticOffQOrg1);
+    w->q_dir[0] = reinterpret_cast<float4*>(base + kStaticOffQDir0);
+    w->q_dir[1] = reinterpret_cast<float4*>(base + kStaticOffQDir1);
+    w->q_link[0] = reinterpret_cast<uint2*>(base + kStaticOffQLink0);
+    w->q_link[1] = reinterpret_cast<uint2*>(base + kStaticOffQLink1);
+    w->node_a = reinterpret_cast<float4*>(base + kStaticOffNodeA);
+    w->node_b = reinterpret_cast<float4*>(base + kStaticOffNodeB);
+    w->node_c = reinterpret_cast<float4*>(base + kStaticOffNodeC);
+    w->node_d = reinterpret_cast<uint2*>(base + kStaticOffNodeD);
+    w->cap_pixels = kStaticPixels;
+    w->shard_cap0 = (uint32_t)(kStaticPerLevel0 / kShards);
+    w->counter_set = 0;
+    w->counters_dirty = true;
+    return RTX_OK;
+}
 
 void free_work(WorkSet* w) {
     for (int i = 0; i < 2; ++i) {
@@ -1804,8 +1882,10 @@ int run_levels(rtx_scene* s, WorkSet& w, Params& p, uint32_t pixels, uint32_t le
     return RTX_OK;
 }
 
+// `fixed`: render through this one work set and allocate nothing (rtx_render_device_static); NULL: the
+// scene's own work sets, grown on demand.
 int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_opts* opts, float* d_rgb, uint8_t* d_rgb8,
-                hipStream_t st, rtx_stats* stats) {
+                hipStream_t st, rtx_stats* stats, WorkSet* fixed = nullptr) {
     int rc = check_camera(cam);
     if (rc) return rc;
     uint32_t depth = (opts && opts->depth) ? opts->depth : kMaxDepth;
@@ -1817,7 +1897,7 @@ int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_opts* opts, float
     const RowPlan plan = plan_rows(cam, opts);
     const uint32_t W = cam->horizontal_size, H = cam->vertical_size;
     const bool compact = opts && opts->compact_rows;
-    const bool profile = opts && opts->profile;
+    const bool profile = opts && opts->profile && !fixed;  // per-launch events come from a growing pool: not on the static path
     const size_t out_rows = compact ? plan.rows_local : H;
 
     // Batch: whole 8-row bands, at most batch_pixels pixels.
@@ -1843,12 +1923,18 @@ int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_opts* opts, float
     int lanes = (int)((opts && opts->lanes) ? opts->lanes : (lanes_env > 0 ? (uint32_t)lanes_env : 0u));
     if (lanes > kLanes) return fail(RTX_E_INVALID, "lanes %d exceeds %d", lanes, kLanes);
     if (lanes == 0) lanes = (s->can_spawn && (uint64_t)plan.rows_local * W >= (1u << 22)) ? kLanes : 1;
-    if (profile || plan.rows_local < 64u) lanes = 1;
+    if (profile || plan.rows_local < 64u || fixed) lanes = 1;
     if (lanes > 1) {
         const uint32_t half = ((plan.rows_local + (uint32_t)lanes - 1u) / (uint32_t)lanes + 7u) & ~7u;
         if (half < rows_per_batch) rows_per_batch = half;
     }
     const uint32_t tiles_x = (W + 7u) / 8u;
+    if (fixed) {  // batches must fit the work set as it is
+        const uint32_t fit = (fixed->cap_pixels / (tiles_x * 8u)) & ~7u;
+        if (fit < 8u)
+            return fail(RTX_E_INVALID, "rtx_render_device_static: width %u exceeds the static work set's maximum of %u pixels", W, kStaticMaxWidth);
+        if (rows_per_batch > fit) rows_per_batch = fit;
+    }
     // The clamp on batch_pixels alone does not bound the node index: tile padding (W = 1 pads to 8) and
     // the rounding of shard capacities add to it.  Shrink the batch until the worst-case node count
     // fits the 30-bit link index (a batch is at least one 8-row band).
@@ -1865,10 +1951,11 @@ int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_opts* opts, float
         static const bool off = getenv("RTX_NO_CANON") != nullptr;  // A/B switch for experiments
         p.canon = (s->canon && cam_canon && !off && !(opts && opts->full_w)) ? 1u : 0u;
     }
-    for (int l = 0; l < lanes; ++l) {
+    for (int l = 0; l < lanes && !fixed; ++l) {
         rc = ensure_work(s, &s->ws[l], cap, p.canon == 0);
         if (rc) return rc;
     }
+    if (fixed) fixed->counters_dirty = true;  // the array is shared by every scene on this GPU and keeps the last call's contents
     if (opts && opts->no_bvh) {
         p.nodes = s->d_nodes_linear;
         p.has_bvh = 0;
@@ -1885,7 +1972,7 @@ int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_opts* opts, float
     p.compact_rows = compact ? 1u : 0u;
     p.canvas = d_rgb;
 
-    HIP_TRY(hipEventRecord(s->ev_begin, st));
+    if (!fixed) HIP_TRY(hipEventRecord(s->ev_begin, st));
     // Canvas starts black (canvas.zig:23-25); rows never rendered stay black.  Every rendered
     // pixel is written exactly once, so only a canvas with unrendered rows needs the fill.
     if (!compact && plan.rows_local < H) HIP_TRY(hipMemsetAsync(d_rgb, 0, out_rows * W * 3 * sizeof(float), st));
@@ -1905,7 +1992,7 @@ int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_opts* opts, float
         p.n_rows = n_rows;
         const uint32_t items = tiles_x * ((n_rows + 7u) / 8u) * 64u;
         const int l = (int)(batch % (uint32_t)lanes);
-        rc = run_levels<true>(s, s->ws[l], p, cap, items, lane_stream[l], profile, batch < (uint32_t)lanes, stats != nullptr);
+        rc = run_levels<true>(s, fixed ? *fixed : s->ws[l], p, cap, items, lane_stream[l], profile, batch < (uint32_t)lanes, stats != nullptr);
         if (rc) return rc;
     }
     const int lanes_used = batch < (uint32_t)lanes ? (int)batch : lanes;
@@ -1920,7 +2007,7 @@ int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_opts* opts, float
         const bool aligned = (reinterpret_cast<uintptr_t>(d_rgb) % 16u == 0u) && (reinterpret_cast<uintptr_t>(d_rgb8) % 4u == 0u);
         hipLaunchKernelGGL(k_quantise, dim3(2048), dim3(256), 0, st, d_rgb, d_rgb8, n, aligned ? n / 4 : (size_t)0);
     }
-    HIP_TRY(hipEventRecord(s->ev_end, st));
+    if (!fixed) HIP_TRY(hipEventRecord(s->ev_end, st));
     HIP_TRY(hipGetLastError());
 
     if (stats) {
@@ -2067,6 +2154,17 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out) {
     HIP_TRY_S(upload((void**)&s->d_materials, desc->materials, sizeof(rtx_material) * desc->n_materials));
     HIP_TRY_S(upload((void**)&s->d_patterns, desc->patterns, sizeof(rtx_pattern) * desc->n_patterns));
     HIP_TRY_S(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
+    // Library set-up on this device (it is current): the device address of the static work set.
+    rc = bind_static_work(device, &s->ws_static);
+    if (rc) return bail(rc);
+    {  // occupancy of every kernel variant this scene can dispatch, so that no render call has to ask
+        const size_t bytes = sizeof(rtx_shape) * s->n_shapes + sizeof(rtx_material) * s->n_materials + sizeof(rtx_pattern) * s->n_patterns;
+        const uint32_t lds = bytes <= kLdsSceneBytes ? (uint32_t)bytes : 0u;
+        for (int cz = 0; cz < 4; ++cz) {
+            s->resident_blocks[cz][0] = resident_blocks<false>(s, lds, (cz & 1) != 0, (cz & 2) != 0);
+            s->resident_blocks[cz][1] = resident_blocks<true>(s, lds, (cz & 1) != 0, (cz & 2) != 0);
+        }
+    }
     for (WorkSet& w : s->ws) {
         HIP_TRY_S(hipMalloc(&w.d_counters, 2 * sizeof(Counters)));
         HIP_TRY_S(hipMalloc(&w.d_totals, sizeof(Totals)));
@@ -2132,6 +2230,17 @@ int rtx_render_device(rtx_scene* s, const rtx_camera* cam, const rtx_opts* opts,
     hipStream_t st = stream ? (hipStream_t)stream : s->stream;
     return render_impl(s, cam, opts, (float*)d_rgb_out, (uint8_t*)d_rgb8_out, st, stats);
 }
+
+int rtx_render_device_static(rtx_scene* s, const rtx_camera* cam, const rtx_opts* opts, void* d_rgb_out, void* d_rgb8_out,
+                             void* stream) {
+    if (!s) return fail(RTX_E_INVALID, "scene is NULL");
+    if (!d_rgb_out) return fail(RTX_E_INVALID, "d_rgb_out is NULL");
+    if (!s->ws_static.d_counters) return fail(RTX_E_HIP, "the static work set was not set up for device %d", s->device);
+    hipStream_t st = stream ? (hipStream_t)stream : s->stream;
+    return render_impl(s, cam, opts, (float*)d_rgb_out, (uint8_t*)d_rgb8_out, st, nullptr, &s->ws_static);
+}
+
+uint32_t rtx_static_max_width(void) { return kStaticMaxWidth; }
 
 int rtx_render(rtx_scene* s, const rtx_camera* cam, const rtx_opts* opts, float* rgb_out, rtx_stats* stats) {
     if (!s) return fail(RTX_E_INVALID, "scene is NULL");
