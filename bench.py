@@ -1,37 +1,47 @@
 #!/usr/bin/env python3
-"""bench.py — BASELINE.json's metric on its configs[1] workload.
+"""bench.py — BASELINE.json's metric on the north-star target.
 
-A step = one pass of the hot path (`Camera.render -> World.colorAt`) over one batch of
-synthetic input: the reference's glass_spheres AND fresnel scenes, each rendered at
-1920x1080 with reflection/refraction depth 5 (BASELINE.json configs[1]), scenes already
-resident in HBM, canvases left on the device (f32 + the u8 quantisation of canvas.zig).
-metric = Mrays/s, a ray being one colorAtInternal or one isShadowed call.
+A step = one pass of the hot path (`Camera.render -> World.colorAt`) over one frame of synthetic
+input: the frozen composite scene (generated teapot mesh + the two glass spheres of
+samples/glass_spheres.zig + the reflective floor of samples/reflective_floor.zig, under the camera and
+light of samples/teapot.zig:21-36) at 3840x2160, reflection/refraction depth 5 — BASELINE.json's
+"Target: teapot + glass scene at 3840x2160, depth 5".  The scene is resident in HBM, the canvas stays
+on the device (f32 + the u8 quantisation of canvas.zig:45-47).  metric = Mrays/s, a ray being one
+colorAtInternal or one isShadowed call.
 
     python bench.py --gpus N --steps K --warmup W
 
-N > 1 (launched by torch.distributed.run, one rank per GPU; every rank holds the scenes):
-* default, "scaling": "weak" — a step is a batch of N frame pairs, rank r renders pair r whole
-  and every u8 canvas is gathered on rank 0 with one RCCL gather per step, overlapped with the
-  next step's rendering (two canvas buffers).  A configs[1] frame takes 0.4 ms on one GPU, below
-  the grain at which splitting it pays (launch floors bound the split at 3.8x on
-  8 GPUs), so frames, not strips, are the unit a node deals out at this size.
-* --split-frames, "scaling": "strong" — north_star's tile sharding: every frame is split into
-  16-row strips, rank r renders the strips s with s % N == r, the strips are gathered and
-  re-interleaved on rank 0 (the tool for 4K/8K frames; bound 6.2x at 8K).
+N > 1 — one rank per GPU (torch.distributed.run; started from here when WORLD_SIZE is not set), every
+rank holds the scene:
+* default, "scaling": "strong" — the metric's "frame ms at 1/2/4/8": every frame is split into 16-row
+  strips, rank r renders the strips s with s % N == r, the u8 strips are gathered on rank 0 (one RCCL
+  gather per step, overlapped with the next step's rendering) and put back in place.
+* --whole-frames, "scaling": "weak" — a step is N frames, rank r renders frame r whole; every u8
+  canvas is gathered on rank 0.
 Time is the max over ranks between two barrier+synchronize pairs; all gathers are inside it.
+With fewer visible GPUs than ranks the run is a REHEARSAL (all ranks on GPU 0, gloo): it checks the N > 1
+code path (what rank 0 received equals the whole-frame render) and says "rehearsal": true — not a measurement.
 
-Also reported in the same JSON line: `roofline` for the dominant kernel (k_trace_shade:
-algorithmic flops from SURVEY §8d's table x device event counts, over the HIP-event duration
-of its launches inside the timed region — every EVENT_EVERY-th timed step carries the events,
-since bracketing every launch slows the step by 14 % — plus the HBM bytes per launch of the
-newest committed PMC pass) and `cpu_baseline` (the oracle — a C port of the
-reference's algorithm, 8 static row bands like src/camera.zig:87-99 — timed on this box on
-a bounded row sample of the same workload; rank 0, N = 1 only).
+Also in the same JSON line (N = 1):
+* `roofline` for the dominant kernel, k_trace_shade: algorithmic flops = SURVEY §8d's table x the
+  device's own event counts (rtx_stats: shape tests by type, gate tests, BVH box and triangle tests,
+  hits, ...), over the HIP-event duration of its launches inside the timed region (every EVENT_EVERY-th
+  timed step carries the events); `frac` is quoted against 78.6 TFLOP/s (SURVEY §8d / BASELINE.md §4:
+  the f32 vector peak for unpacked per-lane code); the same figure against 39.3 (unfused issue rate,
+  what the parity contract allows) and 157.3 (packed FMA, the spec number) is alongside.
+* `configs`: frame ms and Mrays/s of BASELINE.json's other single-GPU configurations, measured in this run.
+* `frame_ms_with_d2h`: the same frame loop with the u8 canvas copied to pinned host memory inside the
+  timed region (double-buffered on a copy stream) — SURVEY §8d's "gather + D2H included" frame time.
+* `cpu_baseline`: the oracle (a C port of the reference's algorithm; 8 static row bands like
+  src/camera.zig:87-99) timed on this box on a bounded row sample of the same frame, and
+  `cpu_baseline_all_threads`: the same on every usable hardware thread.
 """
 import argparse
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -40,32 +50,20 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import numpy as np
-import torch
-
-rta = importlib.import_module("ray-tracer_amd")
-tiling = importlib.import_module("ray-tracer_amd.tiling")
-
-WIDTH, HEIGHT = 1920, 1080
-SCENES = ["glass_spheres", "fresnel"]
+WIDTH, HEIGHT = 3840, 2160
 STRIP_ROWS = 16
-REHEARSE = os.environ.get("RTX_BENCH_REHEARSE") == "1"  # not a measurement mode; see main()
 EVENT_EVERY = 10  # timed steps whose kernel launches are bracketed by HIP events (roofline.avg_launch_ms)
-VALU_PEAK_TFLOPS = 39.3  # 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz, one flop per VALU instruction: FMA
-                         # contraction is forbidden by parity, so a multiply and an add issue
-                         # separately, and an unpacked f32 VALU wave-instruction occupies its SIMD
-                         # for 4 cycles whatever it does — measured on the box, 4.06-4.23 cycles at
-                         # 6 waves per SIMD for mul/add, fma and cmp/cndmask alike
-                         # (tools/microbench/valu_rate.hip, profiles/r01_m_valu_rate.txt).  The spec's
-                         # 157.3 TFLOP/s is that rate x 2 (FMA) x 2 (v_pk_* packed pairs).
-VALU_PEAK_FMA_TFLOPS = 78.6     # same issue rate with every instruction an FMA (not reachable under the parity contract)
+VALU_PEAK_FMA_TFLOPS = 78.6     # the contract denominator: 256 CU x 4 SIMD x 16 lanes x 2.4 GHz x 2 (FMA), unpacked
+VALU_PEAK_UNFUSED_TFLOPS = 39.3  # one flop per VALU instruction: contraction is forbidden by parity (measured 38.7 T lane-ops/s,
+                                 # profiles/r01_m_valu_rate.txt)
 VALU_PEAK_SPEC_TFLOPS = 157.3   # packed FMA, MI355X_MICROARCH.md "Peak FP32 (vector)"
 
-# SURVEY.md §8(d) flop table (add/sub/mul/div/sqrt = 1, fma = 2, pow = 1, compares = 0;
-# 4-lane dot = 7, mat-vec = 28).
+# SURVEY.md §8(d) flop table (add/sub/mul/div/sqrt = 1, fma = 2, pow = 1, compares = 0; 4-lane dot = 7, mat-vec = 28).
 F_RAYGEN = 80
 F_XFORM = 56
 F_TEST = {0: 44, 1: 2, 2: 16, 3: 48, 4: 58, 5: 55}  # sphere, plane, cube, cylinder, cone, triangle
+F_BOX = 16           # AABB / BVH node test
+F_BVH_TRIANGLE = 55  # triangle test on a BVH leaf; the mesh's composed transform is the identity (+0)
 F_PREPARE = 98       # prepareComputations incl. position
 F_SHADOW_SETUP = 24
 F_LIGHTING = 70
@@ -74,81 +72,112 @@ F_REFRACT = 60       # refraction set-up + Schlick
 F_COMBINE = 12
 
 
-def shape_test_flops(world):
-    """Flops to test one ray against every shape of a group-free world."""
-    counts = [world.n_spheres, world.n_planes, world.n_cubes, world.n_cylinders, world.n_cones, world.n_triangles]
-    return sum(n * (F_XFORM + F_TEST[t]) for t, n in enumerate(counts))
-
-
-def trace_shade_flops(world, st):
-    """Algorithmic flops of all k_trace_shade launches of one frame, from device event counts."""
-    per_ray = shape_test_flops(world)
-    rays = sum(st.level_rays[l] for l in range(6))
-    hits = st.rays_shadow
+def trace_shade_flops(st):
+    """Algorithmic flops of all k_trace_shade launches of one frame, from the device's event counts."""
     f = st.rays_primary * F_RAYGEN
-    f += rays * per_ray                       # closest-hit traversal
-    f += hits * (F_PREPARE + F_SHADOW_SETUP + per_ray + F_LIGHTING + F_COMBINE)  # shadow any-hit is a full pass
+    f += sum(st.shape_tests[t] * (F_XFORM + F_TEST[t]) for t in range(6))  # closest-hit and shadow traversals
+    f += (st.gate_tests + st.bvh_box_tests) * F_BOX
+    f += st.bvh_triangle_tests * F_BVH_TRIANGLE
+    f += st.rays_shadow * (F_PREPARE + F_SHADOW_SETUP + F_LIGHTING + F_COMBINE)  # one per hit
     f += st.hits_patterned * F_PATTERN
     f += st.hits_transparent * F_REFRACT
     return f
 
 
 def measured_traffic():
-    """HBM bytes per k_trace_shade launch from the newest committed PMC pass (profiles/r*_traffic.json,
-    written by tools/profile_summarise.py from separate `rocprofv3 --pmc` runs of the same frames:
-    2 x FETCH_SIZE + WRITE_SIZE).  Counters cannot be read from inside this process, so the value is
-    the offline one; None if no pass has been committed."""
+    """HBM bytes per k_trace_shade launch of the headline frame from the newest committed PMC pass
+    (profiles/r*_traffic.json, written by tools/profile_summarise.py from separate `rocprofv3 --pmc`
+    runs: 2 x FETCH_SIZE + WRITE_SIZE).  Counters cannot be read from inside this process, so the
+    value is the offline one; None if no pass of this frame has been committed."""
     import glob
 
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
-    if not files:
-        return None, None
-    with open(files[-1]) as f:
-        return float(json.load(f)["bytes_per_launch"]), os.path.relpath(files[-1], ROOT)
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+        with open(path) as f:
+            d = json.load(f)
+        if d.get("frame") == "composite %dx%d" % (WIDTH, HEIGHT):
+            return float(d["bytes_per_launch"]), os.path.relpath(path, ROOT)
+    return None, None
 
 
-def cpu_baseline(samples):
-    """The oracle (C port of the reference algorithm) on a bounded row sample of the workload."""
+def usable_threads():
+    """Hardware threads this process may use: the affinity mask, capped by the box's own hint
+    (OMP_NUM_THREADS is set to the CPU share of a one-GPU box; os.cpu_count() shows the whole machine)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    hint = os.environ.get("OMP_NUM_THREADS", "")
+    if hint.isdigit() and int(hint) > 0:
+        n = min(n, int(hint))
+    return max(1, n)
+
+
+def cpu_baseline(cam, world, threads, label, n_shapes):
+    """The oracle (C port of the reference algorithm) on a bounded row sample of the headline frame:
+    the first row of each of `threads` static row bands (src/camera.zig:87-99)."""
     import oracle_lib as o
 
-    row_step = 1
-    rays = 0
+    band = HEIGHT // threads
     t0 = time.perf_counter()
-    for s in samples:
-        osamp = o.Sample(s.name, WIDTH, HEIGHT)
-        _, counts = o.render(osamp.camera, osamp.world, rows_quirk=True, row_step=row_step)
-        rays += counts.total
+    _, counts = o.render(cam, world, rows_quirk=True, row_step=band, threads=threads)
     dt = time.perf_counter() - t0
     return {
-        "value": rays / dt / 1e6, "unit": "Mrays/s", "cores": 8, "kind": "port",
-        "sample": "the whole workload once (row step %d; %d rays, %.1f s), 8 threads on static row bands "
-                  "as src/camera.zig:87-99; C restatement of the Zig reference, not the Zig binary" % (row_step, rays, dt),
+        "value": counts.total / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+        "machine_threads": os.cpu_count(),
+        "sample": "%s: the first row of each of %d static row bands of the headline frame (%d of %d rows, %d rays, %.1f s); "
+                  "C restatement of the Zig reference (brute force over all %d shapes, per-test inverse), not the Zig binary"
+                  % (label, threads, threads, HEIGHT, counts.total, dt, n_shapes),
     }
+
+
+def self_launch(args):
+    """--gpus N without a torch.distributed.run environment: start the N ranks from here, before
+    anything in this process touches a GPU, and pass their output through."""
+    import torch  # importing torch and counting devices do not initialise the GPU
+
+    env = dict(os.environ)
+    if torch.cuda.device_count() < args.gpus:
+        env["RTX_BENCH_REHEARSE"] = "1"
+        print("bench.py: %d GPU(s) visible, %d ranks asked for: REHEARSAL (all ranks on GPU 0, gloo) — checks the "
+              "N > 1 path, measures nothing" % (torch.cuda.device_count(), args.gpus), file=sys.stderr, flush=True)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)  # 80 ms of GPU time: short runs sit 1.5 % lower (clock ramp)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--lanes", type=int, default=1, help="rtx_opts.lanes for the timed frames (0 = the library's choice)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline legs")
+    ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configs")
     ap.add_argument("--no-events", action="store_true", help="experiment: no per-launch HIP events in the timed loop")
-    ap.add_argument("--overlap-frames", action="store_true",
-                    help="render the two frames of a step on two streams (+6 %% throughput; per-kernel profiles no longer isolated)")
-    ap.add_argument("--split-frames", action="store_true",
-                    help="N > 1: split every frame into strips across the ranks (strong scaling) instead of dealing whole frames")
+    ap.add_argument("--whole-frames", action="store_true",
+                    help="N > 1: deal whole frames to the ranks (weak scaling) instead of splitting every frame into strips")
     args = ap.parse_args()
+    n = args.gpus
+    if n > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import numpy as np
+    import torch
+
+    rta = importlib.import_module("ray-tracer_amd")
+    tiling = importlib.import_module("ray-tracer_amd.tiling")
+    rehearse = os.environ.get("RTX_BENCH_REHEARSE") == "1"  # not a measurement mode; see the module docstring
+
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    n = args.gpus
     dist = None
     if n > 1:
         import torch.distributed as dist
 
-        assert world == n, "launch with torch.distributed.run --nproc-per-node %d" % n
-        if REHEARSE:  # every rank on GPU 0, gloo between them: exercises this file's N > 1 logic on a 1-GPU box
+        if world_size != n:
+            sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d" % (n, world_size))
+        if rehearse:
             torch.cuda.set_device(0)
             dist.init_process_group("gloo")
         else:
@@ -157,99 +186,84 @@ def main():
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
-    # One explicit stream for renders and gathers (torch's default stream has handle 0, which
-    # the C ABI reads as "use the scene's own stream"): kernels serialise, so the per-launch
-    # HIP-event durations are those of each kernel running alone.
+    # One explicit stream for renders and gathers (torch's default stream has handle 0, which the
+    # C ABI reads as "use the scene's own stream").
     tstream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(tstream)
     stream = tstream.cuda_stream
-    # --overlap-frames: the two frames of a step are independent, so the second scene can render on
-    # a stream of its own and its kernels fill the tails (and the empty deep levels) of the first
-    # one's: +6 % Mrays/s.  Off by default: overlapped kernels stretch each other, and the
-    # per-kernel durations of `rocprofv3 --kernel-trace --stats` over this command (profiles/)
-    # would no longer be those of the kernel running alone, which is what the roofline uses.
-    side = torch.cuda.Stream(device=dev) if args.overlap_frames else None
 
-    samples = [rta.Sample(name, WIDTH, HEIGHT) for name in SCENES]
-    scenes = [rta.Scene(s.world, device=dev.index) for s in samples]
-    cams = [rta.flatten_camera(s.camera) for s in samples]
-    split = n > 1 and args.split_frames
+    obj_text = rta.teapot_obj_text(1)
+    world, cam, keep = rta.composite_scene(obj_text, WIDTH, HEIGHT)
+    scene = rta.Scene(world, device=dev.index)
+    fcam = rta.flatten_camera(cam)
+    split = n > 1 and not args.whole_frames
     strips = (STRIP_ROWS, n, rank) if split else None
-    rows = [rta.rows_for(c, strips=strips) for c in cams]
     max_rows = tiling.slot_rows(HEIGHT, STRIP_ROWS, n) if split else HEIGHT  # equal-size gather slots
-    rgb = [torch.zeros((max_rows, WIDTH, 3), dtype=torch.float32, device=dev) for _ in scenes]
-    # Two u8 canvas sets: while set b travels to rank 0 the next step renders into set 1 - b.
-    rgb8 = [torch.zeros((len(scenes), max_rows, WIDTH, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
-    gdev = torch.device("cpu") if REHEARSE else dev  # gloo gathers host tensors
-    slots = full8 = None
-    if n > 1 and rank == 0:
-        slots = [[torch.zeros(rgb8[0].shape, dtype=torch.uint8, device=gdev) for _ in range(n)] for _ in range(2)]
-        if split:
-            full8 = torch.zeros((len(scenes), HEIGHT, WIDTH, 3), dtype=torch.uint8, device=gdev)
-    pending = {}  # canvas set -> the gather in flight on it
+    rgb = torch.zeros((max_rows, WIDTH, 3), dtype=torch.float32, device=dev)
+    # Two u8 canvas sets: while set b travels (to rank 0, or to the host) the next step renders into set 1 - b.
+    rgb8 = [torch.zeros((1, max_rows, WIDTH, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
+    exchange = whole_slots = None
+    if split:
+        exchange = tiling.StripExchange(HEIGHT, WIDTH, STRIP_ROWS, frames=1, device=dev)
+    elif n > 1:
+        gdev = torch.device("cpu") if rehearse else dev
+        whole_slots = [[torch.zeros(rgb8[0].shape, dtype=torch.uint8, device=gdev) for _ in range(n)] for _ in range(2)] if rank == 0 else None
+    pending = {}
 
     def finish(b):
-        """Wait for the gather of canvas set b; rank 0 of a split run puts the strips back in place."""
-        work, _src = pending.pop(b, (None, None))  # _src: keeps the rehearsal's host copy alive
-        if work is None:
-            return
-        work.wait()  # RCCL: the render stream waits, the host does not
-        if split and rank == 0:
-            for r in range(n):
-                idx = tiling.row_index(HEIGHT, STRIP_ROWS, n, r, True, gdev)
-                if idx.numel():
-                    full8.index_copy_(1, idx, slots[b][r][:, : idx.numel()])
+        if exchange is not None:
+            exchange.finish(b)
+        else:
+            work, _src = pending.pop(b, (None, None))
+            if work is not None:
+                work.wait()
 
     def frame(k, profile):
         b = k & 1
         finish(b)  # set b is free again once its last gather has landed
-        if side is not None:
-            side.wait_stream(tstream)
-        for i, sc in enumerate(scenes):
-            st_i = side.cuda_stream if (side is not None and i == 1 and not profile) else stream
-            sc.render_device(cams[i], rgb[i].data_ptr(), rgb8[b][i].data_ptr(), stream=st_i, strips=strips,
-                             compact_rows=split, profile=profile)
-        if side is not None:
-            tstream.wait_stream(side)
-        if n > 1:  # canvas exchange: every peer sends its u8 canvases (or strips) straight to rank 0
-            src = rgb8[b].cpu() if REHEARSE else rgb8[b]
-            pending[b] = (dist.gather(src, slots[b] if rank == 0 else None, dst=0, async_op=True), src)
+        scene.render_device(fcam, rgb.data_ptr(), rgb8[b].data_ptr(), stream=stream, strips=strips, compact_rows=split,
+                            profile=profile, lanes=args.lanes)
+        if exchange is not None:  # canvas exchange: every peer sends its u8 strips straight to rank 0
+            exchange.submit(b, rgb8[b])
+        elif n > 1:
+            src = rgb8[b].cpu() if rehearse else rgb8[b]
+            pending[b] = (dist.gather(src, whole_slots[b] if rank == 0 else None, dst=0, async_op=True), src)
 
     def fence():
-        for b in list(pending):
+        for b in (0, 1):
             finish(b)
         if n > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Ray counts of this rank's share (deterministic per frame): one counted pass, untimed.
-    stats = [sc.render_device(cams[i], rgb[i].data_ptr(), None, stream=stream, strips=strips, compact_rows=split,
-                              want_stats=True) for i, sc in enumerate(scenes)]
-    rays_local = sum(s.rays_total for s in stats)
+    # Ray and event counts of this rank's share (deterministic per frame): one counted pass, untimed.
+    stats = scene.render_device(fcam, rgb.data_ptr(), None, stream=stream, strips=strips, compact_rows=split, want_stats=True)
+    rays_local = stats.rays_total
 
     for k in range(args.warmup):
         frame(k, False)
     fence()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        # Per-launch HIP events cost ~14 % of the step when every launch is bracketed (they break
-        # the back-to-back dispatch), so every EVENT_EVERY-th timed step carries them.
+        # Per-launch HIP events break the back-to-back dispatch (and force one lane), so only every
+        # EVENT_EVERY-th timed step carries them.
         frame(k, not args.no_events and k % EVENT_EVERY == EVENT_EVERY // 2)
     fence()
     dt = time.perf_counter() - t0
+    prof = scene.profile_collect()
 
-    prof = [sc.profile_collect() for sc in scenes]
-    if REHEARSE and n > 1 and rank == 0:  # what arrived must be the whole-frame renders, byte for byte
-        whole = np.stack([rta.to_ppm_bytes(sc.render(cams[i])[0]) for i, sc in enumerate(scenes)])
-        for b in range(2):
-            if split:
-                assert np.array_equal(full8.numpy(), whole), "re-interleaved strips differ from the whole-frame render"
-            else:
+    if rehearse and n > 1 and rank == 0:  # what arrived must be the whole-frame render, byte for byte
+        whole = rta.to_ppm_bytes(scene.render(fcam)[0])[None]
+        if split:
+            assert np.array_equal(exchange.full.numpy(), whole), "re-interleaved strips differ from the whole-frame render"
+        else:
+            for b in range(2):
                 for r in range(n):
-                    assert np.array_equal(slots[b][r].numpy(), whole), "canvas set %d of rank %d differs" % (b, r)
-        print("rehearsal (%s): the canvases gathered from %d ranks equal the whole-frame renders" % (
+                    assert np.array_equal(whole_slots[b][r].numpy(), whole), "canvas set %d of rank %d differs" % (b, r)
+        print("rehearsal (%s): the canvases gathered from %d ranks equal the whole-frame render" % (
             "split frames" if split else "whole frames", n), file=sys.stderr, flush=True)
-    t = torch.tensor([dt, float(rays_local)], dtype=torch.float64, device=gdev)
+
+    t = torch.tensor([dt, float(rays_local)], dtype=torch.float64, device=torch.device("cpu") if rehearse or n == 1 else dev)
     if n > 1:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -258,15 +272,50 @@ def main():
     else:
         rays_step = float(rays_local)
 
+    extra = {}
+    if n == 1 and rank == 0:
+        # --- the same frame loop with the u8 canvas landing in pinned host memory (SURVEY §8d's frame time) ---
+        copy_stream = torch.cuda.Stream(device=dev)
+        host8 = [torch.empty(rgb8[0].shape, dtype=torch.uint8, pin_memory=True) for _ in range(2)]
+        rendered = [torch.cuda.Event() for _ in range(2)]
+        copied = [torch.cuda.Event() for _ in range(2)]
+
+        def frame_d2h(k):
+            b = k & 1
+            if k >= 2:
+                tstream.wait_event(copied[b])  # the copy of this set's previous frame has left the device buffer
+            scene.render_device(fcam, rgb.data_ptr(), rgb8[b].data_ptr(), stream=stream, lanes=args.lanes)
+            rendered[b].record(tstream)
+            copy_stream.wait_event(rendered[b])
+            with torch.cuda.stream(copy_stream):
+                host8[b].copy_(rgb8[b], non_blocking=True)
+                copied[b].record(copy_stream)
+
+        d2h_steps = max(10, args.steps // 2)
+        for k in range(4):
+            frame_d2h(k)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for k in range(d2h_steps):
+            frame_d2h(k)
+        torch.cuda.synchronize()
+        extra["frame_ms_with_d2h"] = (time.perf_counter() - t1) / d2h_steps * 1e3
+        want8 = rgb8[(d2h_steps - 1) & 1].cpu()
+        assert torch.equal(host8[(d2h_steps - 1) & 1], want8), "the host copy differs from the device canvas"
+
+        # --- BASELINE.json's other single-GPU configurations, a few frames each ---
+        if not args.no_configs:
+            extra["configs"] = other_configs(rta, torch, dev, stream, obj_text)
+
     if rank == 0:
-        ms_trace = sum(p.ms_trace_shade for p in prof)
-        launches = sum(p.launches_trace_shade for p in prof)
-        flops_step = sum(trace_shade_flops(s.world, st) for s, st in zip(samples, stats))
-        avg_ms = ms_trace / max(launches, 1)
-        profiled_steps = len(range(EVENT_EVERY // 2, args.steps, EVENT_EVERY))
-        flops_per_launch = flops_step * profiled_steps / max(launches, 1)
+        launches = prof.launches_trace_shade
+        avg_ms = prof.ms_trace_shade / max(launches, 1)
+        flops_frame = trace_shade_flops(stats)
+        profiled_steps = len(range(EVENT_EVERY // 2, args.steps, EVENT_EVERY)) if not args.no_events else 0
+        flops_per_launch = flops_frame * profiled_steps / max(launches, 1)
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         traffic, traffic_src = measured_traffic() if n == 1 else (None, None)  # the PMC pass is of whole frames
+        frames_per_step = 1 if n == 1 or split else n
         out = {
             "metric": "Mrays/s (primary+shadow+secondary)",
             "value": rays_step * args.steps / dt / 1e6,
@@ -274,43 +323,96 @@ def main():
             "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "strong" if split else "weak",
+            "scaling": "strong" if n == 1 or split else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "glass_spheres + fresnel (samples/*.zig scenes) at 1920x1080, depth 5, one step = "
-                            + ("both frames" if n == 1 or split else "%d frame pairs (one per rank)" % n),
+                "workload": "composite (generated teapot.obj, 1568 triangles + glass_spheres' two spheres + reflective_floor's plane and sphere; "
+                            "camera/light of samples/teapot.zig) at %dx%d, depth 5, one step = %s" % (
+                                WIDTH, HEIGHT, "one frame" if frames_per_step == 1 else "%d frames (one per rank)" % n),
                 "rays_per_step": int(rays_step),
-                "frame_ms": dt / args.steps * 1e3 / (len(SCENES) * (1 if n == 1 or split else n)),
+                "frame_ms": dt / args.steps * 1e3 / frames_per_step,
+                "kernel_variant": {"canonical_w": bool(stats.kernel_flags & 1), "bvh": bool(stats.kernel_flags & 2),
+                                   "lds_tables": bool(stats.kernel_flags & 4), "track_n1": bool(stats.kernel_flags & 8)},
                 "parallelism": "1 GPU" if n == 1 else (
-                    "%d ranks x 16-row strips of every frame, RCCL gather + re-interleave of the u8 strips on rank 0" % n if split
+                    "%d ranks x 16-row strips of every frame, RCCL gather + re-interleave of the u8 strips on rank 0, "
+                    "overlapped with the next step" % n if split
                     else "%d ranks x whole frames, one RCCL gather of the u8 canvases per step on rank 0, overlapped "
                          "with the next step" % n),
             },
             "roofline": {
                 "bound": "valu", "kernel": "k_trace_shade",
-                "achieved": achieved, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / VALU_PEAK_TFLOPS,
-                "frac_of_fma_peak": achieved / VALU_PEAK_FMA_TFLOPS, "frac_of_spec_peak": achieved / VALU_PEAK_SPEC_TFLOPS,
+                "achieved": achieved, "peak": VALU_PEAK_FMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / VALU_PEAK_FMA_TFLOPS,
+                "frac_of_unfused_issue_rate": achieved / VALU_PEAK_UNFUSED_TFLOPS, "frac_of_spec_peak": achieved / VALU_PEAK_SPEC_TFLOPS,
                 "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
-                "flops_per_launch": flops_per_launch, "avg_launch_ms": avg_ms, "launches": launches,
-                "share_of_step": (ms_trace / profiled_steps) / (dt / args.steps * 1e3) if dt > 0 and profiled_steps else None,
-                "note": "f32 VALU roofline (no MFMA: divergent per-lane scalar math); peak = unfused, unpacked f32 issue rate, "
-                        "39.3 T lane-ops/s (measured 38.7: profiles/r01_m_valu_rate.txt); frac_of_fma_peak / frac_of_spec_peak "
-                        "price the same achieved figure against 78.6 (all-FMA) and 157.3 (packed FMA, the spec number); "
-                        "rank 0's launches of every %d-th timed step, bracketed by HIP events on the render stream; "
-                        "traffic = HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE) from the committed PMC pass "
-                        "named in traffic_source" % EVENT_EVERY,
+                "flops_per_launch": flops_per_launch, "flops_per_frame": flops_frame, "avg_launch_ms": avg_ms, "launches": launches,
+                "share_of_step": (prof.ms_trace_shade / profiled_steps) / (dt / args.steps * 1e3) if dt > 0 and profiled_steps else None,
+                "events": {"shape_tests": list(stats.shape_tests), "gate_tests": stats.gate_tests, "bvh_box_tests": stats.bvh_box_tests,
+                           "bvh_triangle_tests": stats.bvh_triangle_tests, "hits": stats.rays_shadow,
+                           "hits_patterned": stats.hits_patterned, "hits_transparent": stats.hits_transparent},
+                "note": "f32 VALU roofline (no MFMA: divergent per-lane scalar math); peak = 78.6 TFLOP/s, the f32 vector peak for "
+                        "unpacked per-lane code (SURVEY 8d); frac_of_unfused_issue_rate prices the same figure against 39.3 "
+                        "(parity forbids FMA contraction: one flop per VALU instruction), frac_of_spec_peak against 157.3 (packed "
+                        "FMA); flops = SURVEY 8d's table x the device's event counts (`events`, of this rank's share of one frame); "
+                        "durations: rank 0's launches of every %d-th timed step, bracketed by HIP events on the render stream (those "
+                        "frames run on one stream); traffic = HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE) from the committed "
+                        "PMC pass named in traffic_source" % EVENT_EVERY,
             },
         }
+        if rehearse and n > 1:
+            out["rehearsal"] = True
+            out["note"] = "all %d ranks shared GPU 0 over gloo: a check of the N > 1 code path, not a measurement" % n
+        out.update(extra)
         if n == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(samples)
+            import oracle_lib as o  # the checker, here as the reported CPU baseline (never the thing measured above)
+
+            ow, ocam, okeep = world, cam, keep  # the oracle reads the same by-value structs
+            out["cpu_baseline"] = cpu_baseline(ocam, ow, 8, "8 threads as src/camera.zig:87", scene.n_shapes)
+            nthreads = usable_threads()
+            if nthreads != 8:
+                out["cpu_baseline_all_threads"] = cpu_baseline(ocam, ow, nthreads, "every usable hardware thread", scene.n_shapes)
         print(json.dumps(out), flush=True)
-    for sc in scenes:
-        sc.close()
+    scene.close()
     if n > 1:
         dist.destroy_process_group()
+
+
+def other_configs(rta, torch, dev, stream, obj_text, frames=10):
+    """Frame ms and Mrays/s of BASELINE.json's other single-GPU configurations (device-resident canvas)."""
+    rows = []
+
+    def measure(label, config, world, cam, w, h):
+        scene = rta.Scene(world, device=dev.index)
+        fcam = rta.flatten_camera(cam)
+        rgb = torch.zeros((h, w, 3), dtype=torch.float32, device=dev)
+        rgb8 = torch.zeros((h, w, 3), dtype=torch.uint8, device=dev)
+        st = scene.render_device(fcam, rgb.data_ptr(), rgb8.data_ptr(), stream=stream, want_stats=True)
+        for _ in range(2):
+            scene.render_device(fcam, rgb.data_ptr(), rgb8.data_ptr(), stream=stream)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(frames):
+            scene.render_device(fcam, rgb.data_ptr(), rgb8.data_ptr(), stream=stream)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / frames * 1e3
+        rows.append({"config": config, "scene": label, "size": "%dx%d" % (w, h), "shapes": scene.n_shapes, "rays_per_frame": st.rays_total,
+                     "frame_ms": ms, "mrays_per_s": st.rays_total / ms / 1e3, "flops_per_frame": trace_shade_flops(st)})
+        scene.close()
+        del rgb, rgb8
+
+    for name in ("glass_spheres", "fresnel"):
+        s = rta.Sample(name, 1920, 1080)
+        measure(name, 1, s.world, s.camera, 1920, 1080)
+    for name in ("cube", "cylinder_world", "cone", "striped_scene"):
+        s = rta.Sample(name, 3840, 2160)
+        measure(name, 2, s.world, s.camera, 3840, 2160)
+    world, cam, keep = rta.teapot_scene(obj_text, 3840, 2160)
+    measure("teapot (generated teapot.obj)", 3, world, cam, 3840, 2160)
+    world, cam, keep = rta.composite_scene(obj_text, 7680, 4320)
+    measure("composite, on one GPU", 4, world, cam, 7680, 4320)
+    return rows
 
 
 if __name__ == "__main__":

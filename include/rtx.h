@@ -169,6 +169,12 @@ typedef struct rtx_stats {
     uint32_t launches_combine;
     uint32_t rows_rendered;
     uint32_t kernel_flags;   /* RTX_KERNEL_*: the k_trace_shade variant this frame's level kernels were */
+    /* Event counts of the frame, closest-hit, predecessor and shadow traversals together (what the
+     * roofline's algorithmic flops are priced from, SURVEY 8d's table): */
+    uint64_t bvh_box_tests;      /* box tests of the triangle-BVH walks (new design; 16 flops like bnd.intersect) */
+    uint64_t bvh_triangle_tests; /* Triangle.intersect calls on BVH leaves (src/triangle.zig:32-50) */
+    uint64_t gate_tests;         /* bnd.intersect calls on group boxes (src/group.zig:58, src/bounds.zig:149-158) */
+    uint64_t shape_tests[6];     /* Shape.intersect calls on linearly tested shapes, by RTX_* type */
 } rtx_stats;
 
 /* rtx_stats.kernel_flags: template flags of the trace+shade kernel a frame dispatched. */

@@ -1361,14 +1361,25 @@ static void* render_internal(void* arg) { /* camera.zig:107-119 */
  * renders only every row_step-th row of each band (bench sampling; other rows
  * stay black).  Threads are the reference's 8 static row bands.
  */
+EXPORT int oracle_render_threads(const rt_camera* cam, const rt_world* world, float* canvas, int rows_quirk,
+                                 uint32_t row_step, uint32_t number_of_threads, rt_ray_counts* counts_out);
+
 EXPORT int oracle_render(const rt_camera* cam, const rt_world* world, float* canvas, int rows_quirk,
                          uint32_t row_step, rt_ray_counts* counts_out) {
-    enum { number_of_threads = 8 };
+    return oracle_render_threads(cam, world, canvas, rows_quirk, row_step, 8 /* camera.zig:87 */, counts_out);
+}
+
+/* The same with the reference's constant `number_of_threads` (camera.zig:87) as a parameter: bench.py's
+ * second CPU leg asks what the reference's static row bands would do on every hardware thread. */
+EXPORT int oracle_render_threads(const rt_camera* cam, const rt_world* world, float* canvas, int rows_quirk,
+                                 uint32_t row_step, uint32_t number_of_threads, rt_ray_counts* counts_out) {
+    enum { max_threads = 1024 };
+    if (number_of_threads == 0 || number_of_threads > max_threads) return -1;
     const uint32_t h = cam->vertical_size, w = cam->horizontal_size;
     memset(canvas, 0, (size_t)w * h * 3 * sizeof(float));
     const uint32_t rows_per_thread = h / number_of_threads;
-    thread_ctx tc[number_of_threads];
-    pthread_t threads[number_of_threads];
+    static __thread thread_ctx tc[max_threads];
+    static __thread pthread_t threads[max_threads];
     if (row_step == 0) row_step = 1;
     for (uint32_t i = 0; i < number_of_threads; ++i) {
         memset(&tc[i], 0, sizeof tc[i]);

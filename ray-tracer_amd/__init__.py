@@ -76,7 +76,9 @@ class RtxStats(C.Structure):
                 ("level_rays", C.c_uint64 * 6), ("nodes", C.c_uint64),
                 ("level_hits", C.c_uint64 * 6), ("hits_patterned", C.c_uint64), ("hits_transparent", C.c_uint64),
                 ("ms_total", f32), ("ms_trace_shade", f32), ("ms_combine", f32),
-                ("launches_trace_shade", u32), ("launches_combine", u32), ("rows_rendered", u32), ("kernel_flags", u32)]
+                ("launches_trace_shade", u32), ("launches_combine", u32), ("rows_rendered", u32), ("kernel_flags", u32),
+                ("bvh_box_tests", C.c_uint64), ("bvh_triangle_tests", C.c_uint64), ("gate_tests", C.c_uint64),
+                ("shape_tests", C.c_uint64 * 6)]
 
     KERNEL_CANONICAL_W, KERNEL_BVH, KERNEL_LDS_TABLES, KERNEL_TRACK_N1 = 1, 2, 4, 8  # rtx.h RTX_KERNEL_*
 

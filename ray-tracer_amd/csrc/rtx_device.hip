@@ -117,9 +117,21 @@ struct ClaimLine {
 };
 static_assert(sizeof(ClaimLine) == 128, "one cache line per shard");
 
+// Event counts of a statistics frame (rtx_stats: what the roofline's algorithmic flops are priced from);
+// written only by the STATS kernels.
+struct StatLine {
+    unsigned long long bvh_box;   // box tests of the triangle-BVH walks (closest hit, predecessor, shadow)
+    unsigned long long bvh_tri;   // triangle tests inside BVH leaves
+    unsigned long long gate;      // group-gate box tests (bnd.intersect, src/group.zig:58)
+    unsigned long long shape[6];  // linear shape tests by RTX_* type, lanes that actually test
+    unsigned long long pad[16 - 9];
+};
+static_assert(sizeof(StatLine) == 128, "one cache line per shard");
+
 struct Counters {
     ShardCounters shard[kShards];
     ClaimLine claims[kShards];
+    StatLine stats[kShards];
 };
 
 struct Totals {
@@ -128,6 +140,25 @@ struct Totals {
     unsigned long long nodes;
     unsigned long long hits_patterned;
     unsigned long long hits_transparent;
+    unsigned long long bvh_box, bvh_tri, gate, shape[6];
+};
+
+// Event tally of one wave of a STATS kernel; the other kernels carry the empty form and pay nothing.
+// bvh_* are per lane (the BVH walk is per lane); gate / shape are wave totals kept by every lane alike.
+template <bool ON>
+struct Tally {
+    uint32_t bvh_box = 0, bvh_tri = 0, gate = 0, shape[6] = {0, 0, 0, 0, 0, 0};
+    RTX_HD void box() { ++bvh_box; }
+    RTX_HD void tri() { ++bvh_tri; }
+    __device__ __forceinline__ void gates(bool lane_tests) { gate += __popcll(__ballot(lane_tests)); }
+    __device__ __forceinline__ void shapes(uint32_t type, bool lane_tests) { shape[type] += __popcll(__ballot(lane_tests)); }
+};
+template <>
+struct Tally<false> {
+    RTX_HD void box() {}
+    RTX_HD void tri() {}
+    __device__ __forceinline__ void gates(bool) {}
+    __device__ __forceinline__ void shapes(uint32_t, bool) {}
 };
 
 struct Params {
@@ -588,8 +619,8 @@ __device__ __forceinline__ void intersect_shape(V& v, const RT_CONST rtx_shape& 
 // (or runs out of nodes), then the lanes test their leaf triangles together.  With a single
 // loop the lanes that sit on a leaf would run the long triangle test while all the others,
 // still walking boxes, idle through it — and the other way round.
-template <bool C, class V>
-RTX_HD void traverse_bvh(V& v, const Params& p, uint32_t root, V4 o, V4 d) {
+template <bool C, class V, class T>
+RTX_HD void traverse_bvh(V& v, T& tally, const Params& p, uint32_t root, V4 o, V4 d) {
     const float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
     const rtx_bvh::Node* nodes = p.bvh_nodes;
     // The tree comes in rtx_bvh::kLayouts threaded layouts of equal size, one per octant of the
@@ -607,6 +638,7 @@ RTX_HD void traverse_bvh(V& v, const Params& p, uint32_t root, V4 o, V4 d) {
             const float4 b = *reinterpret_cast<const float4*>(&nodes[n].bmax[0]);
             const uint32_t skip = bits_of(a.w), leaf = bits_of(b.w);
             v.visited_node();
+            tally.box();
             // slab test; a NaN (0 * inf) drops out of fmin/fmax like in the reference's checkAxis.
             // Kept as (bound - o) * (1 / d): the contracted form fma(bound, 1/d, -o/d) loses the
             // small difference bound - o against a large o / d and would cull wrongly.
@@ -635,6 +667,7 @@ RTX_HD void traverse_bvh(V& v, const Params& p, uint32_t root, V4 o, V4 d) {
             const float4 q2 = *reinterpret_cast<const float4*>(&tr->e1[0]);
             const uint32_t shape = bits_of(q0.w), flags = bits_of(q1.w);
             v.tested_triangle();
+            tally.tri();
             V4 ro = o, rd = d;
             if (!(flags & kShapeIdentity)) {
                 const float* inv = p.shapes[shape].inverse;
@@ -657,14 +690,15 @@ RTX_HD void traverse_bvh(V& v, const Params& p, uint32_t root, V4 o, V4 d) {
 // through scalar loads); a lane whose ray failed a group's box is parked until the loop
 // leaves that group's subtree.  `lane_on` is false for padding lanes.  A node whose triangle
 // run has a BVH tests only its `n_linear` leading shapes linearly.
-template <bool C, bool BVH, class V>
-__device__ __forceinline__ void traverse(V& v, const Params& p, V4 o, V4 d, bool lane_on) {
+template <bool C, bool BVH, class V, class T>
+__device__ __forceinline__ void traverse(V& v, T& tally, const Params& p, V4 o, V4 d, bool lane_on) {
     uint32_t parked_until = lane_on ? 0u : kNone;  // node index at which this lane wakes up
     const RT_CONST rtx_node* nodes = as_const(p.nodes);
     const RT_CONST rtx_shape* shapes = as_const(p.shapes);
     for (uint32_t n = 0; n < p.n_nodes; ++n) {
         const RT_CONST rtx_node& node = nodes[n];
         bool active = n >= parked_until && !v.done();
+        tally.gates(active && node.has_bounds);
         if (active && node.has_bounds && !bounds_hit(node, o, d)) {
             parked_until = node.skip;
             active = false;
@@ -673,25 +707,29 @@ __device__ __forceinline__ void traverse(V& v, const Params& p, V4 o, V4 d, bool
         const uint32_t bvh_root = BVH ? node.reserved[0] : 0u;  // root + 1, 0 = no BVH
         const uint32_t first = node.first_shape;
         const uint32_t last = first + (bvh_root ? node.reserved[1] : node.n_shapes);
-        for (uint32_t s = first; s < last; ++s) intersect_shape<C>(v, shapes[s], s, o, d, active);
-        if (BVH && bvh_root && active) traverse_bvh<C>(v, p, bvh_root - 1u, o, d);
+        for (uint32_t s = first; s < last; ++s) {
+            tally.shapes(shapes[s].type, active);
+            intersect_shape<C>(v, shapes[s], s, o, d, active);
+        }
+        if (BVH && bvh_root && active) traverse_bvh<C>(v, tally, p, bvh_root - 1u, o, d);
     }
 }
 
 // The gates again, for the BVH triangles only: the predecessor walk of the lanes in `lane_on`.
-template <bool C>
-__device__ __forceinline__ void traverse_pred(PredVisitor& v, const Params& p, V4 o, V4 d, bool lane_on) {
+template <bool C, class T>
+__device__ __forceinline__ void traverse_pred(PredVisitor& v, T& tally, const Params& p, V4 o, V4 d, bool lane_on) {
     uint32_t parked_until = lane_on ? 0u : kNone;
     const RT_CONST rtx_node* nodes = as_const(p.nodes);
     for (uint32_t n = 0; n < p.n_nodes; ++n) {
         const RT_CONST rtx_node& node = nodes[n];
         bool active = n >= parked_until;
+        tally.gates(active && node.has_bounds);
         if (active && node.has_bounds && !bounds_hit(node, o, d)) {
             parked_until = node.skip;
             active = false;
         }
         const uint32_t bvh_root = node.reserved[0];
-        if (bvh_root && active) traverse_bvh<C>(v, p, bvh_root - 1u, o, d);
+        if (bvh_root && active) traverse_bvh<C>(v, tally, p, bvh_root - 1u, o, d);
     }
 }
 
@@ -992,7 +1030,7 @@ struct LdsScene {
 #ifndef RTX_WAVES_PER_EU_NOBVH
 #define RTX_WAVES_PER_EU_NOBVH 6
 #endif
-template <bool GEN, bool TRACK, bool LDS, bool C, bool BVH>
+template <bool GEN, bool TRACK, bool LDS, bool C, bool BVH, bool STATS>
 __global__ __launch_bounds__(256)
 __attribute__((amdgpu_waves_per_eu((BVH || !C) ? RTX_WAVES_PER_EU : RTX_WAVES_PER_EU_NOBVH,
                                    (BVH || !C) ? RTX_WAVES_PER_EU : RTX_WAVES_PER_EU_NOBVH))) void k_trace_shade(const Params p, const uint32_t level) {
@@ -1018,9 +1056,9 @@ __attribute__((amdgpu_waves_per_eu((BVH || !C) ? RTX_WAVES_PER_EU : RTX_WAVES_PE
     // launch clears the other for the batch after it (everything that used that set finished
     // before this kernel started), so frames that do not ask for statistics need neither a fill
     // nor k_accumulate between batches.
-    static_assert(sizeof(Counters) == 2u * kShards * 128u && 2u * kShards <= 16u * 256u, "one thread of the first blocks per line");
-    if (root && blockIdx.x * 256u + threadIdx.x < 2u * kShards) {
-        // lines [0, kShards) are the shard counters, [kShards, 2 kShards) the claim lines (struct Counters)
+    static_assert(sizeof(Counters) == 3u * kShards * 128u && 3u * kShards <= 16u * 256u, "one thread of the first blocks per line");
+    if (root && blockIdx.x * 256u + threadIdx.x < 3u * kShards) {
+        // lines [0, kShards) are the shard counters, then the claim lines, then the statistics lines (struct Counters)
         uint4* line = reinterpret_cast<uint4*>(p.counters_next) + (size_t)(blockIdx.x * 256u + threadIdx.x) * (sizeof(ShardCounters) / sizeof(uint4));
 #pragma unroll
         for (int k = 0; k < (int)(sizeof(ShardCounters) / sizeof(uint4)); ++k) line[k] = make_uint4(0u, 0u, 0u, 0u);
@@ -1055,6 +1093,7 @@ __attribute__((amdgpu_waves_per_eu((BVH || !C) ? RTX_WAVES_PER_EU : RTX_WAVES_PE
     const uint32_t node_base = p.node_off[level] + shard * (p.shard_cap0 << (level * p.level_shift));
 
     uint32_t local_hits = 0, local_patterned = 0, local_transparent = 0;
+    Tally<STATS> tally;
     DIAG_DECL
     // Chunks of 64 rays are handed out on demand — one returning atomic on the shard's line per
     // iteration — instead of dealt in advance (wave w: chunks w, w + n_waves, ...): with the static
@@ -1125,7 +1164,7 @@ __attribute__((amdgpu_waves_per_eu((BVH || !C) ? RTX_WAVES_PER_EU : RTX_WAVES_PE
         // colorAtInternal: world.intersect + hit (src/world.zig:85-95)
         ClosestVisitor<TRACK> cv;
         cv.init();
-        traverse<C, BVH>(cv, p, o, d, on);
+        traverse<C, BVH>(cv, tally, p, o, d, on);
         const bool is_hit = on && cv.c.idx != kNone;
         if (TRACK && BVH) {
             // n1 matters only where the hit material is transparent (src/world.zig:151,
@@ -1133,7 +1172,7 @@ __attribute__((amdgpu_waves_per_eu((BVH || !C) ? RTX_WAVES_PER_EU : RTX_WAVES_PE
             const bool need = is_hit && tab.materials[tab.shapes[cv.c.idx].material].transparency != 0.0f;
             if (__ballot(need) != 0ull) {
                 PredVisitor pv{cv.c.pred_t, cv.c.pred_idx};
-                traverse_pred<C>(pv, p, o, d, need);
+                traverse_pred<C>(pv, tally, p, o, d, need);
                 if (need) {
                     cv.c.pred_t = pv.pred_t;
                     cv.c.pred_idx = pv.pred_idx;
@@ -1176,7 +1215,7 @@ __attribute__((amdgpu_waves_per_eu((BVH || !C) ? RTX_WAVES_PER_EU : RTX_WAVES_PE
         ShadowVisitor sv;
         sv.distance = shadow_distance;
         sv.found = false;
-        traverse<C, BVH>(sv, p, over_point, shadow_dir, is_hit);
+        traverse<C, BVH>(sv, tally, p, over_point, shadow_dir, is_hit);
         DIAG_PHASE(3);  // shadow traversal
 
         bool spawn_reflect = false, spawn_refract = false, use_schlick = false;
@@ -1286,6 +1325,22 @@ __attribute__((amdgpu_waves_per_eu((BVH || !C) ? RTX_WAVES_PER_EU : RTX_WAVES_PE
         if (local_patterned | local_transparent)
             atomicAdd(&sc->hit_kinds, (static_cast<unsigned long long>(local_transparent) << 32) | local_patterned);
     }
+    if constexpr (STATS) {
+        uint32_t box = tally.bvh_box, tri = tally.bvh_tri;
+        for (int off = 32; off > 0; off >>= 1) {
+            box += __shfl_down(box, off);
+            tri += __shfl_down(tri, off);
+        }
+        if (lane == 0) {
+            StatLine* sl = &p.counters->stats[shard];
+            if (box) atomicAdd(&sl->bvh_box, (unsigned long long)box);
+            if (tri) atomicAdd(&sl->bvh_tri, (unsigned long long)tri);
+            if (tally.gate) atomicAdd(&sl->gate, (unsigned long long)tally.gate);
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+                if (tally.shape[k]) atomicAdd(&sl->shape[k], (unsigned long long)tally.shape[k]);
+        }
+    }
 }
 
 // Interior nodes of one level, after every deeper level has delivered into their slots.
@@ -1313,8 +1368,15 @@ __global__ __launch_bounds__(256) void k_combine(const Params p, const uint32_t 
 __global__ void k_accumulate(Counters* c, Totals* t, uint32_t level0_rays, uint32_t depth, uint32_t reset) {
     const uint32_t k = threadIdx.x;  // one wave; lane k owns shards k, k + 64, ...
     unsigned long long rays[kLevels] = {}, hits[kLevels] = {}, nodes = 0, patterned = 0, transparent = 0;
+    unsigned long long ev[9] = {};  // StatLine's nine counts
     for (uint32_t sh = k; sh < kShards; sh += 64u) {
         ShardCounters* sc = &c->shard[sh];
+        unsigned long long* sl = reinterpret_cast<unsigned long long*>(&c->stats[sh]);
+#pragma unroll
+        for (int e = 0; e < 9; ++e) {
+            ev[e] += sl[e];
+            sl[e] = 0ull;
+        }
 #pragma unroll
         for (int l = 0; l < kLevels; ++l) {
             const unsigned long long a = sc->alloc[l];
@@ -1339,9 +1401,15 @@ __global__ void k_accumulate(Counters* c, Totals* t, uint32_t level0_rays, uint3
         nodes += __shfl_down(nodes, off);
         patterned += __shfl_down(patterned, off);
         transparent += __shfl_down(transparent, off);
+#pragma unroll
+        for (int e = 0; e < 9; ++e) ev[e] += __shfl_down(ev[e], off);
     }
     if (k == 0) {
         if (reset) *t = Totals{};
+        t->bvh_box += ev[0];
+        t->bvh_tri += ev[1];
+        t->gate += ev[2];
+        for (int e = 0; e < 6; ++e) t->shape[e] += ev[3 + e];
         t->level_rays[0] += level0_rays;
         for (uint32_t l = 0; l < depth; ++l) t->level_rays[l + 1] += rays[l];
         for (uint32_t l = 0; l <= depth; ++l) t->level_hits[l] += hits[l];
@@ -1635,25 +1703,28 @@ RowPlan plan_rows(const rtx_camera* cam, const rtx_opts* o) {
 
 // The k_trace_shade instantiation a frame uses, picked from run-time flags.
 using TraceKernel = void (*)(const Params, const uint32_t);
-template <bool GEN, bool TRACK, bool LDS>
-TraceKernel trace_kernel3(bool canon, bool bvh) {
-    if (bvh) return canon ? k_trace_shade<GEN, TRACK, LDS, true, true> : k_trace_shade<GEN, TRACK, LDS, false, true>;
-    return canon ? k_trace_shade<GEN, TRACK, LDS, true, false> : k_trace_shade<GEN, TRACK, LDS, false, false>;
+// Run-time flags -> template flags, one at a time, in k_trace_shade's parameter order.
+template <bool... Flags>
+TraceKernel pick_kernel() {
+    return k_trace_shade<Flags...>;
+}
+template <bool... Flags, class... Rest>
+TraceKernel pick_kernel(bool f, Rest... rest) {
+    return f ? pick_kernel<Flags..., true>(rest...) : pick_kernel<Flags..., false>(rest...);
 }
 template <bool GEN>
-TraceKernel trace_kernel(bool track, bool lds, bool canon, bool bvh) {
-    if (track) return lds ? trace_kernel3<GEN, true, true>(canon, bvh) : trace_kernel3<GEN, true, false>(canon, bvh);
-    return lds ? trace_kernel3<GEN, false, true>(canon, bvh) : trace_kernel3<GEN, false, false>(canon, bvh);
+TraceKernel trace_kernel(bool track, bool lds, bool canon, bool bvh, bool stats = false) {
+    return pick_kernel<GEN>(track, lds, canon, bvh, stats);
 }
 
 template <bool GEN>
-void launch_trace(const rtx_scene* s, const Params& p, uint32_t level, uint32_t blocks, hipStream_t st) {
+void launch_trace(const rtx_scene* s, const Params& p, uint32_t level, uint32_t blocks, hipStream_t st, bool stats) {
     // At the depth limit (remaining == 0) nothing refracts (src/world.zig:151) and the Schlick
     // reflectance only weighs two black children (src/world.zig:71-78), so n1 is dead there —
     // provided the reflectance is finite (0 * R must be 0): s->finite_schlick.  The last level
     // holds the most rays and runs the kernel without predecessor tracking.
     const bool track = s->track_n1 && !(level == p.depth && s->finite_schlick);
-    hipLaunchKernelGGL(trace_kernel<GEN>(track, p.lds_bytes != 0, p.canon != 0, p.has_bvh != 0), dim3(blocks), dim3(256), p.lds_bytes, st, p, level);
+    hipLaunchKernelGGL(trace_kernel<GEN>(track, p.lds_bytes != 0, p.canon != 0, p.has_bvh != 0, stats), dim3(blocks), dim3(256), p.lds_bytes, st, p, level);
 }
 
 // Resident 256-thread blocks per CU of a variant (registers and LDS decide).
@@ -1862,8 +1933,9 @@ int run_levels(rtx_scene* s, WorkSet& w, Params& p, uint32_t pixels, uint32_t le
         // Level 0 knows its size; deeper levels read theirs on the device and grid-stride.
         const uint32_t blocks = grid_for(level == 0 ? level0_items : ((uint64_t)pixels << (level * p.level_shift)), GEN && level == 0);
         mark(0);
-        if (level == 0) launch_trace<GEN>(s, p, level, blocks, st);
-        else launch_trace<false>(s, p, level, blocks, st);
+        // frames that read statistics back run the counting variants (event tallies for rtx_stats)
+        if (level == 0) launch_trace<GEN>(s, p, level, blocks, st, want_totals);
+        else launch_trace<false>(s, p, level, blocks, st, want_totals);
         mark(-1);
     }
     for (int level = (int)last_level - 1; level >= 0; --level) {
@@ -2023,6 +2095,10 @@ int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_opts* opts, float
             t.nodes += part[l].nodes;
             t.hits_patterned += part[l].hits_patterned;
             t.hits_transparent += part[l].hits_transparent;
+            t.bvh_box += part[l].bvh_box;
+            t.bvh_tri += part[l].bvh_tri;
+            t.gate += part[l].gate;
+            for (int k = 0; k < 6; ++k) t.shape[k] += part[l].shape[k];
         }
         // k_accumulate counts tile padding at level 0; the rays that exist are the pixels.
         stats->rays_primary = (uint64_t)plan.rows_local * W;
@@ -2038,6 +2114,10 @@ int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_opts* opts, float
         stats->nodes = t.nodes;
         stats->hits_patterned = t.hits_patterned;
         stats->hits_transparent = t.hits_transparent;
+        stats->bvh_box_tests = t.bvh_box;
+        stats->bvh_triangle_tests = t.bvh_tri;
+        stats->gate_tests = t.gate;
+        for (int k = 0; k < 6; ++k) stats->shape_tests[k] = t.shape[k];
         stats->rows_rendered = plan.rows_local;
         stats->kernel_flags = (p.canon ? RTX_KERNEL_CANONICAL_W : 0u) | (p.has_bvh ? RTX_KERNEL_BVH : 0u) |
                               (p.lds_bytes ? RTX_KERNEL_LDS_TABLES : 0u) | (s->track_n1 ? RTX_KERNEL_TRACK_N1 : 0u);
@@ -2335,11 +2415,12 @@ int rtx_bvh_selftest(const rtx_scene_desc* desc, const float* origins, const flo
             const V4 d = v4(directions[4 * r], directions[4 * r + 1], directions[4 * r + 2], directions[4 * r + 3]);
             CountingVisitor cv;
             cv.init();
-            traverse_bvh<false>(cv, p, root, o, d);
+            Tally<false> no_tally;
+            traverse_bvh<false>(cv, no_tally, p, root, o, d);
             g_selftest_nodes += cv.nodes;
             g_selftest_tris += cv.tris;
             PredVisitor pv{-INFINITY, kNone};
-            traverse_bvh<false>(pv, p, root, o, d);
+            traverse_bvh<false>(pv, no_tally, p, root, o, d);
             ClosestVisitor<true> ref;
             ref.init();
             PredVisitor pref{-INFINITY, kNone};

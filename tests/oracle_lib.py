@@ -85,14 +85,15 @@ class Sample:
             self.handle = None
 
 
-def render(camera, world, rows_quirk=True, row_step=1):
-    """oracle_render -> (canvas float32 [H, W, 3], RayCounts)."""
+def render(camera, world, rows_quirk=True, row_step=1, threads=8):
+    """oracle_render -> (canvas float32 [H, W, 3], RayCounts).  threads = the reference's
+    number_of_threads (src/camera.zig:87): static row bands of H // threads rows."""
     L = lib()
     h, w = camera.vertical_size, camera.horizontal_size
     canvas = np.zeros((h, w, 3), dtype=np.float32)
     counts = st.RayCounts()
-    rc = L.oracle_render(C.byref(camera), C.byref(world), canvas.ctypes.data_as(C.POINTER(C.c_float)),
-                         1 if rows_quirk else 0, row_step, C.byref(counts))
+    rc = L.oracle_render_threads(C.byref(camera), C.byref(world), canvas.ctypes.data_as(C.POINTER(C.c_float)),
+                                 1 if rows_quirk else 0, row_step, threads, C.byref(counts))
     assert rc == 0
     return canvas, counts
 

@@ -1,0 +1,45 @@
+"""bench.py as the driver runs it: the N = 1 line carries the contract's fields, and `--gpus 2` without a
+torch.distributed.run environment starts its own ranks — on a one-GPU box as a rehearsal (both ranks on
+GPU 0, gloo) that checks what rank 0 gathered against the whole-frame render."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*args):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0]), r.stderr
+
+
+def test_single_gpu_line_names_the_north_star_frame():
+    d, _ = _bench("--steps", "20", "--warmup", "2", "--no-cpu", "--no-configs")
+    assert d["n_gpus"] == 1 and d["unit"] == "Mrays/s" and d["dtype"] == "f32" and d["vs_baseline"] is None
+    assert "composite" in d["config"]["workload"] and "3840x2160" in d["config"]["workload"]
+    assert d["config"]["kernel_variant"] == {"canonical_w": True, "bvh": True, "lds_tables": False, "track_n1": True}
+    assert abs(d["value"] - d["config"]["rays_per_step"] / d["ms_per_step"] / 1e3) < 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["peak"] == 78.6 and r["launches"] > 0 and 0 < r["frac"] < 1 and r["events"]["bvh_box_tests"] > 0
+    assert abs(r["frac"] - r["achieved"] / 78.6) < 1e-12 and d["frame_ms_with_d2h"] > 0
+
+
+def test_gpus_2_starts_its_own_ranks_and_rehearses_on_one_gpu():
+    import torch
+
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("more than one GPU visible: --gpus 2 would be a real run")
+    d, err = _bench("--gpus", "2", "--steps", "4", "--warmup", "1")
+    assert d["n_gpus"] == 2 and d.get("rehearsal") is True and d["scaling"] == "strong"
+    assert "16-row strips" in d["config"]["parallelism"]
+    assert "equal the whole-frame render" in err
+    d, err = _bench("--gpus", "2", "--steps", "4", "--warmup", "1", "--whole-frames")
+    assert d["scaling"] == "weak" and "equal the whole-frame render" in err

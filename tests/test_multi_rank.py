@@ -48,15 +48,65 @@ def _worker(rank, world, port, height, width, strip, ok):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("height,strip", [(1080, 16), (70, 16)])
-def test_two_ranks_gather_reassembles_the_canvas(height, strip):
+def _free_port():
+    import socket
+
+    with socket.socket() as s:  # a fresh port per run: a fixed one may still sit in TIME_WAIT from the run before
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(target, world, *args):
     ctx = mp.get_context("spawn")
     ok = ctx.Value("i", 0)
-    port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, height, 48, strip, ok)) for r in range(2)]
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port) + args + (ok,)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
-        p.join(120)
+        p.join(180)
         assert p.exitcode == 0
-    assert ok.value == 1
+    return ok.value
+
+
+@pytest.mark.parametrize("height,strip", [(1080, 16), (70, 16)])
+def test_two_ranks_gather_reassembles_the_canvas(height, strip):
+    assert _run(_worker, 2, height, 48, strip) == 1
+
+
+def _render_worker(rank, world, port, name, width, height, strip, steps, ok):
+    """bench.py's split-frame loop (tiling.StripExchange) with a real renderer behind it: the oracle
+    renders the frame (tests may use it; there is no GPU here), each rank keeps only its strips'
+    rows, and after `steps` double-buffered exchanges rank 0 must hold the whole frame's PPM bytes."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import oracle_lib as o
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        s = rta.Sample(name, width, height)
+        canvas, _ = o.render(s.camera, s.world)
+        whole = o.to_ppm_bytes(canvas)
+        rows = tiling.rows_of_rank(height, strip, world, rank)
+        assert len(rows) == rta.rows_for(s.camera, strips=(strip, world, rank))
+        ex = tiling.StripExchange(height, width, strip, frames=1)
+        assert ex.local_rows == len(rows)
+        local = [torch.zeros((1, ex.slot_rows, width, 3), dtype=torch.uint8) for _ in range(2)]
+        for k in range(steps):
+            b = k & 1
+            ex.finish(b)
+            local[b].fill_(k)                                   # leftovers of an earlier step must not survive
+            local[b][0, : len(rows)] = torch.from_numpy(whole[rows])  # "render" this rank's strips, compact
+            ex.submit(b, local[b])
+        ex.drain()
+        dist.barrier()
+        if rank == 0:
+            ok.value = int(np.array_equal(ex.full[0].numpy(), whole) and whole.any())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,name,width,height,strip", [(2, "glass_spheres", 64, 48, 16), (3, "sphere_world", 50, 70, 8)])
+def test_strip_exchange_of_rendered_frames(world, name, width, height, strip):
+    assert _run(_render_worker, world, name, width, height, strip, 5) == 1

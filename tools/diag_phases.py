@@ -8,20 +8,19 @@ import importlib
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
-rta = importlib.import_module("ray-tracer_amd")
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _scenes import load, rta  # noqa: E402
 rta.LIB_PATH = os.path.join(rta.HERE, "libraytracer_amd_diag.so")
 L = rta.lib()
 name = sys.argv[1] if len(sys.argv) > 1 else "glass_spheres"
 w = int(sys.argv[2]) if len(sys.argv) > 2 else 1920
 h = int(sys.argv[3]) if len(sys.argv) > 3 else 1080
-s = rta.Sample(name, w, h)
-scene = rta.Scene(s.world)
-scene.render(s.camera)
+world, cam, keep = load(name, w, h)
+scene = rta.Scene(world)
+scene.render(cam)
 buf = (C.c_ulonglong * 16)()
 L.rtx_diag_read(buf, 1)
-canvas, st = scene.render(s.camera)
+canvas, st = scene.render(cam)
 L.rtx_diag_read(buf, 1)
 names = ["ray fetch/gen", "closest traversal", "prepare + shadow setup", "shadow traversal", "lighting/refract/schlick",
          "leaf delivery", "slot allocation atomic", "node + child stores"]

@@ -19,7 +19,7 @@ for line in sys.stdin:
 for r in rows:
     n = r["name"]
     m = re.search(r"k_trace_shadeI((?:Lb\dE)+)", n)
-    names = ["GEN", "TRACK", "LDS", "C", "BVH", "X5", "X6"]
+    names = ["GEN", "TRACK", "LDS", "C", "BVH", "STATS", "X6"]
     tag = "trace " + " ".join(k + v for k, v in zip(names, re.findall(r"Lb(\d)E", m.group(1)))) if m else n[:40]
     print("%-36s VGPR %3s  spill %3s  scratch %5s  occ %s  SGPR %s" % (tag, r.get("VGPRs"), r.get("VGPRs Spill"), r.get("ScratchSize"), r.get("Occupancy"), r.get("TotalSGPRs")))
 '
