@@ -209,7 +209,7 @@ class Sample:
         self.camera = L.rt_sample_camera(self.handle).contents
 
     def __del__(self):
-        if getattr(self, "handle", None):
+        if getattr(self, "handle", None) and lib is not None:  # `lib` is gone when the interpreter shuts down
             lib().rt_sample_destroy(self.handle)
             self.handle = None
 
@@ -232,7 +232,7 @@ class ObjFile:
         self.n_groups = lib().rt_obj_group_count(h)
 
     def __del__(self):
-        if getattr(self, "handle", None):
+        if getattr(self, "handle", None) and lib is not None:
             lib().rt_obj_free(self.handle)
             self.handle = None
 
@@ -302,7 +302,7 @@ class FlatScene:
         self.desc = lib().rt_flat_desc(h).contents
 
     def __del__(self):
-        if getattr(self, "handle", None):
+        if getattr(self, "handle", None) and lib is not None:
             lib().rt_flat_free(self.handle)
             self.handle = None
 
@@ -318,7 +318,7 @@ class Scene:
         self.n_shapes = flat.desc.n_shapes
 
     def close(self):
-        if getattr(self, "handle", None):
+        if getattr(self, "handle", None) and lib is not None:
             lib().rtx_scene_destroy(self.handle)
             self.handle = None
 

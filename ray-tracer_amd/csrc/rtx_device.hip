@@ -62,9 +62,13 @@ int fail(int code, const char* fmt, ...) {
 
 constexpr float kEpsilon = 0.00001f;  // src/tuple.zig:10
 constexpr uint32_t kNone = 0xFFFFFFFFu;
-constexpr uint32_t kLinkIndexMask = 0x3FFFFFFFu;
+// A link names whoever waits for a colour: a canvas pixel (rays of level 0, nodes of level 0) or a
+// ray-tree node (index) plus which of its two child slots the colour is for.
+constexpr uint32_t kLinkIndexMask = 0x0FFFFFFFu;
+constexpr uint32_t kLinkOwnSingleBit = 1u << 28;  // in a node's link: the node itself has one child (k_combine skips it)
+constexpr uint32_t kLinkSingleBit = 1u << 29;  // the parent node named by this link has no other child (see deliver)
 constexpr uint32_t kLinkSlotBit = 1u << 30;    // 0: reflected slot, 1: refracted slot
-constexpr uint32_t kLinkSchlickBit = 1u << 31; // node combines with Schlick reflectance
+constexpr uint32_t kLinkSchlickBit = 1u << 31; // in a node's link: the node combines with Schlick reflectance
 constexpr int kMaxDepth = 5;                   // src/world.zig:20
 constexpr int kLevels = kMaxDepth + 1;
 
@@ -951,20 +955,37 @@ __device__ __forceinline__ WaveAlloc wave_alloc(ShardCounters* sc, uint32_t leve
 }
 
 // Hand a finished colour to whoever asked for it: the canvas at the root
-// (canvas.writePixel, src/canvas.zig:34-36), otherwise the parent's reflected / refracted
-// slot, scaled by the parent's reflective / transparency (src/world.zig:142,185).
+// (canvas.writePixel, src/canvas.zig:34-36), otherwise the parent, scaled by the parent's
+// reflective / transparency (src/world.zig:142,185).
+// A parent with two children keeps the colour in its reflected / refracted slot until k_combine
+// has both.  A parent whose only child this is needs no slot and no combine pass: its other
+// colour is the black of src/world.zig:131,151, so shadeHit's sum (src/world.zig:71-78) can be
+// evaluated right here — the same f32 operations on the same values as k_combine's — and the
+// result handed on to ITS parent, and so on up a chain of single-child nodes (most interior
+// nodes of a scene with mirrors are such nodes: a reflective floor has one child per hit).
 __device__ __forceinline__ void deliver(const Params& p, bool root, uint32_t link, float weight, Color c) {
-    if (root) {
-        float* px = p.canvas + 3ull * (link & kLinkIndexMask);
-        px[0] = c.r;
-        px[1] = c.g;
-        px[2] = c.b;
-    } else {
+    const Color black{0.0f, 0.0f, 0.0f};
+    while (!root) {
         const uint32_t parent = link & kLinkIndexMask;
-        // one 16-byte store per child: three scattered dword stores cost a 32-byte partial write each
-        float4* slot = (link & kLinkSlotBit) ? &p.node_c[parent] : &p.node_b[parent];
-        *slot = make_float4(c.r * weight, c.g * weight, c.b * weight, 0.0f);
+        const Color cw{c.r * weight, c.g * weight, c.b * weight};
+        if (!(link & kLinkSingleBit)) {
+            // one 16-byte store per child: three scattered dword stores cost a 32-byte partial write each
+            float4* slot = (link & kLinkSlotBit) ? &p.node_c[parent] : &p.node_b[parent];
+            *slot = make_float4(cw.r, cw.g, cw.b, 0.0f);
+            return;
+        }
+        const float4 a = p.node_a[parent];
+        const uint2 dd = p.node_d[parent];
+        const bool refracted = (link & kLinkSlotBit) != 0u;
+        c = combine(Color{a.x, a.y, a.z}, refracted ? black : cw, refracted ? cw : black, (dd.x & kLinkSchlickBit) != 0u, a.w);
+        root = parent < p.node_off[1];  // a node of level 0 answers to the canvas
+        link = dd.x;
+        weight = __uint_as_float(dd.y);
     }
+    float* px = p.canvas + 3ull * (link & kLinkIndexMask);
+    px[0] = c.r;
+    px[1] = c.g;
+    px[2] = c.b;
 }
 
 // ------------------------------------------------------------------------ kernels
@@ -1290,24 +1311,26 @@ __attribute__((amdgpu_waves_per_eu((BVH || !C) ? RTX_WAVES_PER_EU : RTX_WAVES_PE
         if (interior) {
             node = node_base + wa.node_base + __popcll(m_node & below);
             p.node_a[node] = make_float4(surface.r, surface.g, surface.b, reflectance);
-            const uint32_t bits = (link & (kLinkIndexMask | kLinkSlotBit)) | (use_schlick ? kLinkSchlickBit : 0u);
+            // the node's own link upwards: index, slot and whether ITS parent is a single-child node
+            const uint32_t bits = (link & (kLinkIndexMask | kLinkSlotBit | kLinkSingleBit)) | (use_schlick ? kLinkSchlickBit : 0u) |
+                                  ((spawn_reflect != spawn_refract) ? kLinkOwnSingleBit : 0u);
             p.node_d[node] = make_uint2(bits, __float_as_uint(weight));
-            // a slot without a child stays black (src/world.zig:131,151); the others are written by their child
-            if (!spawn_reflect) p.node_b[node] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (!spawn_refract) p.node_c[node] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
+        // Children of a node with one child say so in their link: that node is folded where its child's
+        // colour is delivered (deliver) and k_combine skips it.
+        const uint32_t single = (spawn_reflect != spawn_refract) ? kLinkSingleBit : 0u;
         if (spawn_reflect) {
             const uint32_t slot = out_base + wa.refl_base + __popcll(m_refl & below);
-            p.q_org[qo][slot] = make_float4(over_point.x, over_point.y, over_point.z, C ? __uint_as_float(node) : over_point.w);
+            p.q_org[qo][slot] = make_float4(over_point.x, over_point.y, over_point.z, C ? __uint_as_float(node | single) : over_point.w);
             p.q_dir[qo][slot] = make_float4(reflectv.x, reflectv.y, reflectv.z, C ? reflective : reflectv.w);
-            if (!C) p.q_link[qo][slot] = make_uint2(node, __float_as_uint(reflective));
+            if (!C) p.q_link[qo][slot] = make_uint2(node | single, __float_as_uint(reflective));
         }
         if (spawn_refract) {
             const uint32_t slot = out_top - (wa.refr_base + __popcll(m_refr & below));
             p.q_org[qo][slot] =
-                make_float4(under_point.x, under_point.y, under_point.z, C ? __uint_as_float(node | kLinkSlotBit) : under_point.w);
+                make_float4(under_point.x, under_point.y, under_point.z, C ? __uint_as_float(node | kLinkSlotBit | single) : under_point.w);
             p.q_dir[qo][slot] = make_float4(refract_dir.x, refract_dir.y, refract_dir.z, C ? transparency : refract_dir.w);
-            if (!C) p.q_link[qo][slot] = make_uint2(node | kLinkSlotBit, __float_as_uint(transparency));
+            if (!C) p.q_link[qo][slot] = make_uint2(node | kLinkSlotBit | single, __float_as_uint(transparency));
         }
         DIAG_PHASE(7);  // node + child-ray stores
     }
@@ -1354,9 +1377,10 @@ __global__ __launch_bounds__(256) void k_combine(const Params p, const uint32_t 
     const uint32_t node_base = p.node_off[level] + shard * (p.shard_cap0 << (level * p.level_shift));
     for (uint32_t i = (wave / kShards) * 64u + lane; i < count; i += (n_waves / kShards) * 64u) {
         const uint32_t node = node_base + i;
-        const float4 a = p.node_a[node], b = p.node_b[node], c = p.node_c[node];
         const uint2 dd = p.node_d[node];
         const uint32_t bits = dd.x;
+        if (bits & kLinkOwnSingleBit) continue;  // folded where its only child's colour was delivered
+        const float4 a = p.node_a[node], b = p.node_b[node], c = p.node_c[node];
         const Color out = combine(Color{a.x, a.y, a.z}, Color{b.x, b.y, b.z}, Color{c.x, c.y, c.z},
                                   (bits & kLinkSchlickBit) != 0u, a.w);
         deliver(p, root, bits, __uint_as_float(dd.y), out);
