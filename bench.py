@@ -334,7 +334,8 @@ def main():
                 "rays_per_step": int(rays_step),
                 "frame_ms": dt / args.steps * 1e3 / frames_per_step,
                 "kernel_variant": {"canonical_w": bool(stats.kernel_flags & 1), "bvh": bool(stats.kernel_flags & 2),
-                                   "lds_tables": bool(stats.kernel_flags & 4), "track_n1": bool(stats.kernel_flags & 8)},
+                                   "lds_tables": bool(stats.kernel_flags & 4), "track_n1": bool(stats.kernel_flags & 8),
+                                   "lds_hit_records": bool(stats.kernel_flags & 16)},
                 "parallelism": "1 GPU" if n == 1 else (
                     "%d ranks x 16-row strips of every frame, RCCL gather + re-interleave of the u8 strips on rank 0, "
                     "overlapped with the next step" % n if split

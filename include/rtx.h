@@ -181,8 +181,9 @@ typedef struct rtx_stats {
 enum {
     RTX_KERNEL_CANONICAL_W = 1u << 0, /* w lanes left out (every point w == 1, every vector w == 0 exactly) */
     RTX_KERNEL_BVH         = 1u << 1, /* some gate's triangle run is walked through its BVH */
-    RTX_KERNEL_LDS_TABLES  = 1u << 2, /* per-lane scene tables staged in LDS */
-    RTX_KERNEL_TRACK_N1    = 1u << 3  /* n1 predecessor tracked (some material is transparent) */
+    RTX_KERNEL_LDS_TABLES  = 1u << 2, /* every per-lane scene table staged in LDS */
+    RTX_KERNEL_TRACK_N1    = 1u << 3, /* n1 predecessor tracked (some material is transparent) */
+    RTX_KERNEL_LDS_HIT_RECORDS = 1u << 4 /* 16-byte hit records, materials and patterns staged in LDS; shape records in global memory */
 };
 
 typedef struct rtx_scene rtx_scene; /* opaque; owns the device copies */

@@ -80,7 +80,7 @@ class RtxStats(C.Structure):
                 ("bvh_box_tests", C.c_uint64), ("bvh_triangle_tests", C.c_uint64), ("gate_tests", C.c_uint64),
                 ("shape_tests", C.c_uint64 * 6)]
 
-    KERNEL_CANONICAL_W, KERNEL_BVH, KERNEL_LDS_TABLES, KERNEL_TRACK_N1 = 1, 2, 4, 8  # rtx.h RTX_KERNEL_*
+    KERNEL_CANONICAL_W, KERNEL_BVH, KERNEL_LDS_TABLES, KERNEL_TRACK_N1, KERNEL_LDS_HIT_RECORDS = 1, 2, 4, 8, 16  # rtx.h RTX_KERNEL_*
 
     @property
     def rays_total(self):

@@ -138,6 +138,20 @@ struct Counters {
     StatLine stats[kShards];
 };
 
+// What shading a hit needs before (and for planes and mesh triangles: instead of) the 160-byte shape
+// record: 16 bytes per shape, so that the table of a mesh of ~2000 triangles sits in LDS and a hit on
+// a larger one costs one cache line instead of three.
+struct HitRec {
+    float n[3];     // finished world-space normal of a plane / triangle (kHitWorldNormal), else unused
+    uint32_t bits;  // material [0, 20) | RTX_* type [20, 23) | kHit* flags
+};
+constexpr uint32_t kHitMaterialMask = (1u << 20) - 1u;
+constexpr uint32_t kHitTypeShift = 20;
+constexpr uint32_t kHitIdentity = 1u << 23;     // the shape's inverse is exactly the identity
+constexpr uint32_t kHitDiagonal = 1u << 24;     // ... is diag(a, b, c) plus a translation
+constexpr uint32_t kHitWorldNormal = 1u << 25;  // `n` is the hit's normal whatever the point
+static_assert(sizeof(HitRec) == 16, "one 16-byte load per hit");
+
 struct Totals {
     unsigned long long level_rays[kLevels];
     unsigned long long level_hits[kLevels];
@@ -167,6 +181,7 @@ struct Tally<false> {
 
 struct Params {
     const rtx_shape* shapes;
+    const HitRec* hitrecs;  // one per shape
     const rtx_node* nodes;
     const rtx_material* materials;
     const rtx_pattern* patterns;
@@ -176,7 +191,8 @@ struct Params {
     uint32_t n_shapes;
     uint32_t n_materials;
     uint32_t n_patterns;
-    uint32_t lds_bytes;  // > 0: the scene tables are staged in this much dynamic LDS
+    uint32_t lds_bytes;  // > 0: scene tables are staged in this much dynamic LDS (which ones: k_trace_shade's TAB)
+    uint32_t tab_mode;   // TAB of the kernels this frame runs
     uint32_t track_n1;  // scene has a transparent material: track the n1 predecessor
     uint32_t canon;     // this frame runs the canonical-w kernels (ray records are 32 bytes)
     uint32_t has_bvh;   // some gate node of `nodes` carries a triangle BVH
@@ -742,16 +758,17 @@ __device__ __forceinline__ void traverse_pred(PredVisitor& v, T& tally, const Pa
 // Shape.normalAt for the hit shape (per-lane record).
 // world -> object point for the per-lane hit shape; the diagonal form when the shape allows it
 // (a per-lane branch: waves whose hits all sit on scaled / translated shapes skip the general one).
+// `bits` are the hit record's flags: an identity shape's full record is never read.
 template <bool C>
-__device__ __forceinline__ V4 to_object(const rtx_shape& sh, V4 world_point) {
-    if (sh.flags & kShapeIdentity) return world_point;
-    if (C && (sh.flags & kShapeDiagonal)) return mul_point_diag(sh.inverse, world_point);
+__device__ __forceinline__ V4 to_object(uint32_t bits, const rtx_shape& sh, V4 world_point) {
+    if (bits & kHitIdentity) return world_point;
+    if (C && (bits & kHitDiagonal)) return mul_point_diag(sh.inverse, world_point);
     return mul_point<C>(sh.inverse, world_point);
 }
 template <bool C>
-__device__ __forceinline__ V4 normal_to_world(const rtx_shape& sh, V4 n) {
-    if (sh.flags & kShapeIdentity) return n;
-    if (C && (sh.flags & kShapeDiagonal)) return mul_dir_diag(sh.inverse, n);  // a diagonal block is its own transpose
+__device__ __forceinline__ V4 normal_to_world(uint32_t bits, const rtx_shape& sh, V4 n) {
+    if (bits & kHitIdentity) return n;
+    if (C && (bits & kHitDiagonal)) return mul_dir_diag(sh.inverse, n);  // a diagonal block is its own transpose
     return mul_mat_t<C>(sh.inverse, n);
 }
 
@@ -769,13 +786,14 @@ __host__ inline void world_normal_of(const rtx_shape& sh, float out[4]) {
     out[3] = w.w;
 }
 
+// Shapes whose normal depends on the point (spheres, cubes, cylinders, cones); planes and triangles
+// are answered from the hit record by the caller.
 template <bool C>
-__device__ __forceinline__ V4 normal_at(const rtx_shape& sh, V4 world_point) {
-    if (sh.flags & kShapeWorldNormal) return v4(sh.normal[0], sh.normal[1], sh.normal[2], C ? 0.0f : sh.normal[3]);
+__device__ __forceinline__ V4 normal_at(uint32_t bits, const rtx_shape& sh, V4 world_point) {
     V4 object_normal;
-    switch (sh.type) {
+    switch ((bits >> kHitTypeShift) & 7u) {
     case RTX_SPHERE: {  // src/sphere.zig:56-82
-        const V4 object_point = to_object<C>(sh, world_point);
+        const V4 object_point = to_object<C>(bits, sh, world_point);
         object_normal = sub(object_point, v4(0.0f, 0.0f, 0.0f, 1.0f));
         break;
     }
@@ -783,16 +801,16 @@ __device__ __forceinline__ V4 normal_at(const rtx_shape& sh, V4 world_point) {
         object_normal = v4(0.0f, 1.0f, 0.0f, 0.0f);
         break;
     case RTX_CUBE: {  // src/cube.zig:28-44 — w is NOT reset before normalising
-        const V4 object_point = to_object<C>(sh, world_point);
+        const V4 object_point = to_object<C>(bits, sh, world_point);
         const float x = fabsf(object_point.x), y = fabsf(object_point.y), z = fabsf(object_point.z);
         const float maxc = fmaxf(x, fmaxf(y, z));
         if (maxc == x) object_normal = v4(object_point.x, 0.0f, 0.0f, 0.0f);
         else if (maxc == y) object_normal = v4(0.0f, object_point.y, 0.0f, 0.0f);
         else object_normal = v4(0.0f, 0.0f, object_point.z, 0.0f);
-        return normalize<C>(normal_to_world<C>(sh, object_normal));
+        return normalize<C>(normal_to_world<C>(bits, sh, object_normal));
     }
     case RTX_CYLINDER: {  // src/cylinder.zig:73-92
-        const V4 object_point = to_object<C>(sh, world_point);
+        const V4 object_point = to_object<C>(bits, sh, world_point);
         const float distance = object_point.x * object_point.x + object_point.z * object_point.z;
         if (distance < 1.0f && object_point.y >= sh.maximum - kEpsilon) object_normal = v4(0.0f, 1.0f, 0.0f, 0.0f);
         else if (distance < 1.0f && object_point.y <= sh.minimum + kEpsilon) object_normal = v4(0.0f, -1.0f, 0.0f, 0.0f);
@@ -800,7 +818,7 @@ __device__ __forceinline__ V4 normal_at(const rtx_shape& sh, V4 world_point) {
         break;
     }
     case RTX_CONE: {  // src/cone.zig:84-105
-        const V4 object_point = to_object<C>(sh, world_point);
+        const V4 object_point = to_object<C>(bits, sh, world_point);
         const float distance = object_point.x * object_point.x + object_point.z * object_point.z;
         if (distance < sh.maximum * sh.maximum && object_point.y >= sh.maximum - kEpsilon) {
             object_normal = v4(0.0f, 1.0f, 0.0f, 0.0f);
@@ -816,7 +834,7 @@ __device__ __forceinline__ V4 normal_at(const rtx_shape& sh, V4 world_point) {
         object_normal = v4(sh.normal[0], sh.normal[1], sh.normal[2], sh.normal[3]);
         break;
     }
-    V4 world_normal = normal_to_world<C>(sh, object_normal);
+    V4 world_normal = normal_to_world<C>(bits, sh, object_normal);
     world_normal.w = 0.0f;
     return normalize<C>(world_normal);
 }
@@ -835,8 +853,8 @@ struct Color {
 
 // Pattern.atShape (src/pattern.zig:23-51)
 template <bool C>
-__device__ __forceinline__ Color pattern_at_shape(const rtx_pattern& pat, const rtx_shape& sh, V4 world_point) {
-    const V4 object_point = to_object<C>(sh, world_point);
+__device__ __forceinline__ Color pattern_at_shape(const rtx_pattern& pat, uint32_t bits, const rtx_shape& sh, V4 world_point) {
+    const V4 object_point = to_object<C>(bits, sh, world_point);
     const V4 pt = mul_point<C>(pat.inverse, object_point);  // only x, y, z are read
     const Color a{pat.a[0], pat.a[1], pat.a[2]}, b{pat.b[0], pat.b[1], pat.b[2]};
     switch (pat.color_map) {
@@ -887,10 +905,10 @@ __device__ __forceinline__ float pow_lanes(float x, float y) {
 
 // Material.lighting (src/material.zig:40-102)
 template <bool C>
-__device__ __forceinline__ Color lighting(const Params& p, const rtx_pattern* patterns, const rtx_material& m,
+__device__ __forceinline__ Color lighting(const Params& p, const rtx_pattern* patterns, const rtx_material& m, uint32_t bits,
                                           const rtx_shape& sh, V4 point, V4 light_direction, V4 eye, V4 normal, bool in_shadow) {
     Color color;
-    if (m.pattern >= 0) color = pattern_at_shape<C>(patterns[m.pattern], sh, point);
+    if (m.pattern >= 0) color = pattern_at_shape<C>(patterns[m.pattern], bits, sh, point);
     else color = Color{m.color[0], m.color[1], m.color[2]};
 
     const Color li{p.light_intensity[0], p.light_intensity[1], p.light_intensity[2]};
@@ -1030,13 +1048,19 @@ constexpr uint32_t kLdsSceneBytes = 32768;  // 5 blocks per CU (the mesh kernels
 
 struct LdsScene {
     const rtx_shape* shapes;
+    const HitRec* hit;
     const rtx_material* materials;
     const rtx_pattern* patterns;
 };
+// Which per-lane tables a kernel stages in LDS (template parameter TAB):
+constexpr int kTabGlobal = 0;  // none: every per-lane record comes from global memory (meshes beyond ~2000 triangles)
+constexpr int kTabAll = 1;     // hit records, shape records, materials, patterns (analytic scenes, meshes up to ~180 triangles)
+constexpr int kTabHit = 2;     // hit records, materials, patterns; the 160-byte shape records stay in global memory and
+                               // are read only for hits whose normal or pattern needs the inverse (meshes up to ~2000 triangles)
 
 // One ray-tree level.  GEN: level-0 rays come from the camera (rayForPixel,
-// src/camera.zig:70-82) instead of the queue.  TRACK: keep the n1 predecessor.  LDS: the
-// scene tables fit in LDS (p.lds_bytes of dynamic shared memory).  C: canonical w lanes (see
+// src/camera.zig:70-82) instead of the queue.  TRACK: keep the n1 predecessor.  TAB: which scene
+// tables are staged in LDS (kTab*, p.lds_bytes of dynamic shared memory).  C: canonical w lanes (see
 // dot<C>); rays then travel as two float4 (origin.xyz + link, direction.xyz + weight = 32 B)
 // instead of origin, direction and a link/weight pair (40 B).  BVH: some gate carries a triangle
 // BVH (scenes without one get kernels without the traversal code and its registers).
@@ -1051,26 +1075,30 @@ struct LdsScene {
 #ifndef RTX_WAVES_PER_EU_NOBVH
 #define RTX_WAVES_PER_EU_NOBVH 6
 #endif
-template <bool GEN, bool TRACK, bool LDS, bool C, bool BVH, bool STATS>
+template <int TAB, bool GEN, bool TRACK, bool C, bool BVH, bool STATS>
 __global__ __launch_bounds__(256)
 __attribute__((amdgpu_waves_per_eu((BVH || !C) ? RTX_WAVES_PER_EU : RTX_WAVES_PER_EU_NOBVH,
                                    (BVH || !C) ? RTX_WAVES_PER_EU : RTX_WAVES_PER_EU_NOBVH))) void k_trace_shade(const Params p, const uint32_t level) {
     extern __shared__ uint4 lds_raw[];
-    LdsScene tab{p.shapes, p.materials, p.patterns};
-    if (LDS) {
-        // [shapes][materials][patterns], all record sizes are multiples of 16 bytes.
-        const uint32_t n_sh = p.n_shapes * (uint32_t)(sizeof(rtx_shape) / 16), n_ma = p.n_materials * (uint32_t)(sizeof(rtx_material) / 16),
-                       n_pa = p.n_patterns * (uint32_t)(sizeof(rtx_pattern) / 16);
+    LdsScene tab{p.shapes, p.hitrecs, p.materials, p.patterns};
+    if (TAB != kTabGlobal) {
+        // [hit records][shapes, if TAB == kTabAll][materials][patterns], all record sizes are multiples of 16 bytes.
+        const uint32_t n_hr = p.n_shapes * (uint32_t)(sizeof(HitRec) / 16);
+        const uint32_t n_sh = TAB == kTabAll ? p.n_shapes * (uint32_t)(sizeof(rtx_shape) / 16) : 0u;
+        const uint32_t n_ma = p.n_materials * (uint32_t)(sizeof(rtx_material) / 16), n_pa = p.n_patterns * (uint32_t)(sizeof(rtx_pattern) / 16);
+        const uint4* g_hr = reinterpret_cast<const uint4*>(p.hitrecs);
         const uint4* g_sh = reinterpret_cast<const uint4*>(p.shapes);
         const uint4* g_ma = reinterpret_cast<const uint4*>(p.materials);
         const uint4* g_pa = reinterpret_cast<const uint4*>(p.patterns);
-        for (uint32_t k = threadIdx.x; k < n_sh; k += blockDim.x) lds_raw[k] = g_sh[k];
-        for (uint32_t k = threadIdx.x; k < n_ma; k += blockDim.x) lds_raw[n_sh + k] = g_ma[k];
-        for (uint32_t k = threadIdx.x; k < n_pa; k += blockDim.x) lds_raw[n_sh + n_ma + k] = g_pa[k];
+        for (uint32_t k = threadIdx.x; k < n_hr; k += blockDim.x) lds_raw[k] = g_hr[k];
+        for (uint32_t k = threadIdx.x; k < n_sh; k += blockDim.x) lds_raw[n_hr + k] = g_sh[k];
+        for (uint32_t k = threadIdx.x; k < n_ma; k += blockDim.x) lds_raw[n_hr + n_sh + k] = g_ma[k];
+        for (uint32_t k = threadIdx.x; k < n_pa; k += blockDim.x) lds_raw[n_hr + n_sh + n_ma + k] = g_pa[k];
         __syncthreads();
-        tab.shapes = reinterpret_cast<const rtx_shape*>(lds_raw);
-        tab.materials = reinterpret_cast<const rtx_material*>(lds_raw + n_sh);
-        tab.patterns = reinterpret_cast<const rtx_pattern*>(lds_raw + n_sh + n_ma);
+        tab.hit = reinterpret_cast<const HitRec*>(lds_raw);
+        if (TAB == kTabAll) tab.shapes = reinterpret_cast<const rtx_shape*>(lds_raw + n_hr);
+        tab.materials = reinterpret_cast<const rtx_material*>(lds_raw + n_hr + n_sh);
+        tab.patterns = reinterpret_cast<const rtx_pattern*>(lds_raw + n_hr + n_sh + n_ma);
     }
     const bool root = level == 0;
     // Two counter sets alternate between batches: while this batch allocates from one, its first
@@ -1190,7 +1218,7 @@ __attribute__((amdgpu_waves_per_eu((BVH || !C) ? RTX_WAVES_PER_EU : RTX_WAVES_PE
         if (TRACK && BVH) {
             // n1 matters only where the hit material is transparent (src/world.zig:151,
             // src/intersection.zig:165): only those lanes look for a predecessor among the meshes.
-            const bool need = is_hit && tab.materials[tab.shapes[cv.c.idx].material].transparency != 0.0f;
+            const bool need = is_hit && tab.materials[tab.hit[cv.c.idx].bits & kHitMaterialMask].transparency != 0.0f;
             if (__ballot(need) != 0ull) {
                 PredVisitor pv{cv.c.pred_t, cv.c.pred_idx};
                 traverse_pred<C>(pv, tally, p, o, d, need);
@@ -1206,11 +1234,15 @@ __attribute__((amdgpu_waves_per_eu((BVH || !C) ? RTX_WAVES_PER_EU : RTX_WAVES_PE
         // (src/world.zig:55,97-106), per lane.
         V4 point = o, normal = d, over_point = o, shadow_dir = d;
         float n1 = 1.0f, n2 = 1.0f, shadow_distance = 0.0f, cos_i = 0.0f;
+        HitRec hr{{0.0f, 0.0f, 0.0f}, 0u};
         if (is_hit) {
             ++local_hits;
-            const rtx_shape& sh = tab.shapes[cv.c.idx];
+            hr = tab.hit[cv.c.idx];
             point = add(o, muls(d, cv.c.t));  // ray.position, src/ray.zig:9-11
-            normal = normal_at<C>(sh, point);
+            // Planes and triangles have one normal (finished at upload, world_normal_of); the others
+            // evaluate normalAt on their full record.
+            if (hr.bits & kHitWorldNormal) normal = v4(hr.n[0], hr.n[1], hr.n[2], 0.0f);
+            else normal = normal_at<C>(hr.bits, tab.shapes[cv.c.idx], point);
             // dot(normal, eye) decides the flip (src/intersection.zig:79); the dots the shading takes
             // later with the final normal — dot(eye, normal), dot(ray.direction, normal) — are this
             // value or its exact negation (products commute, negation commutes with rounding).
@@ -1221,8 +1253,8 @@ __attribute__((amdgpu_waves_per_eu((BVH || !C) ? RTX_WAVES_PER_EU : RTX_WAVES_PE
                 cos_i = -dn;
             }
             // n1 / n2 (src/intersection.zig:92-159, see Closest above)
-            if (TRACK && cv.c.pred_idx != kNone) n1 = tab.materials[tab.shapes[cv.c.pred_idx].material].refractive_index;
-            n2 = tab.materials[sh.material].refractive_index;
+            if (TRACK && cv.c.pred_idx != kNone) n1 = tab.materials[tab.hit[cv.c.pred_idx].bits & kHitMaterialMask].refractive_index;
+            n2 = tab.materials[hr.bits & kHitMaterialMask].refractive_index;
             over_point = add(point, muls(normal, p.over_eps));
             const V4 lp = v4(p.light_position[0], p.light_position[1], p.light_position[2], p.light_position[3]);
             const V4 to_light = sub(lp, over_point);
@@ -1244,8 +1276,8 @@ __attribute__((amdgpu_waves_per_eu((BVH || !C) ? RTX_WAVES_PER_EU : RTX_WAVES_PE
         Color surface{0.0f, 0.0f, 0.0f};
         V4 reflectv = d, under_point = o, refract_dir = d;
         if (is_hit) {
-            const rtx_shape& sh = tab.shapes[cv.c.idx];
-            const rtx_material& m = tab.materials[sh.material];
+            const rtx_shape& sh = tab.shapes[cv.c.idx];  // read only if a pattern needs the shape's inverse
+            const rtx_material& m = tab.materials[hr.bits & kHitMaterialMask];
             const V4 eye = neg(d);
             // reflect(ray.direction, normal) (src/intersection.zig:88): dot(direction, normal) == -cos_i
             reflectv = sub(d, muls(muls(normal, -cos_i), 2.0f));
@@ -1254,7 +1286,7 @@ __attribute__((amdgpu_waves_per_eu((BVH || !C) ? RTX_WAVES_PER_EU : RTX_WAVES_PE
             local_patterned += m.pattern >= 0 ? 1u : 0u;
             local_transparent += (m.transparency != 0.0f && remaining != 0u) ? 1u : 0u;  // refraction set-up evaluated
             // shadeHitInternal (src/world.zig:54-79): Phong is evaluated at over_point.
-            surface = lighting<C>(p, tab.patterns, m, sh, over_point, shadow_dir, eye, normal, sv.found);
+            surface = lighting<C>(p, tab.patterns, m, hr.bits, sh, over_point, shadow_dir, eye, normal, sv.found);
             // reflectedColorInternal (src/world.zig:126-143)
             spawn_reflect = remaining != 0u && m.reflective != 0.0f;
             // refractedColorInternal (src/world.zig:149-186) and schlick (src/intersection.zig:161-180)
@@ -1524,6 +1556,7 @@ struct rtx_scene {
     int device = 0;
     hipStream_t stream = nullptr;
     rtx_shape* d_shapes = nullptr;
+    HitRec* d_hitrecs = nullptr;         // one per shape (build_hitrecs)
     rtx_node* d_nodes = nullptr;         // gates with BVH links (reserved[0] = root + 1, reserved[1] = linear shapes)
     rtx_node* d_nodes_linear = nullptr;  // the same gates, brute force only (rtx_opts.no_bvh)
     rtx_bvh::Node* d_bvh_nodes = nullptr;
@@ -1728,17 +1761,19 @@ RowPlan plan_rows(const rtx_camera* cam, const rtx_opts* o) {
 // The k_trace_shade instantiation a frame uses, picked from run-time flags.
 using TraceKernel = void (*)(const Params, const uint32_t);
 // Run-time flags -> template flags, one at a time, in k_trace_shade's parameter order.
-template <bool... Flags>
+template <int TAB, bool... Flags>
 TraceKernel pick_kernel() {
-    return k_trace_shade<Flags...>;
+    return k_trace_shade<TAB, Flags...>;
 }
-template <bool... Flags, class... Rest>
+template <int TAB, bool... Flags, class... Rest>
 TraceKernel pick_kernel(bool f, Rest... rest) {
-    return f ? pick_kernel<Flags..., true>(rest...) : pick_kernel<Flags..., false>(rest...);
+    return f ? pick_kernel<TAB, Flags..., true>(rest...) : pick_kernel<TAB, Flags..., false>(rest...);
 }
 template <bool GEN>
-TraceKernel trace_kernel(bool track, bool lds, bool canon, bool bvh, bool stats = false) {
-    return pick_kernel<GEN>(track, lds, canon, bvh, stats);
+TraceKernel trace_kernel(bool track, uint32_t tab, bool canon, bool bvh, bool stats = false) {
+    if (tab == (uint32_t)kTabAll) return pick_kernel<kTabAll, GEN>(track, canon, bvh, stats);
+    if (tab == (uint32_t)kTabHit) return pick_kernel<kTabHit, GEN>(track, canon, bvh, stats);
+    return pick_kernel<kTabGlobal, GEN>(track, canon, bvh, stats);
 }
 
 template <bool GEN>
@@ -1748,14 +1783,14 @@ void launch_trace(const rtx_scene* s, const Params& p, uint32_t level, uint32_t 
     // provided the reflectance is finite (0 * R must be 0): s->finite_schlick.  The last level
     // holds the most rays and runs the kernel without predecessor tracking.
     const bool track = s->track_n1 && !(level == p.depth && s->finite_schlick);
-    hipLaunchKernelGGL(trace_kernel<GEN>(track, p.lds_bytes != 0, p.canon != 0, p.has_bvh != 0, stats), dim3(blocks), dim3(256), p.lds_bytes, st, p, level);
+    hipLaunchKernelGGL(trace_kernel<GEN>(track, p.tab_mode, p.canon != 0, p.has_bvh != 0, stats), dim3(blocks), dim3(256), p.lds_bytes, st, p, level);
 }
 
 // Resident 256-thread blocks per CU of a variant (registers and LDS decide).
 template <bool GEN>
-int resident_blocks(const rtx_scene* s, uint32_t lds_bytes, bool canon, bool bvh) {
+int resident_blocks(const rtx_scene* s, uint32_t tab_mode, uint32_t lds_bytes, bool canon, bool bvh) {
     int n = 0;
-    const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_kernel<GEN>(s->track_n1, lds_bytes != 0, canon, bvh), 256, lds_bytes);
+    const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_kernel<GEN>(s->track_n1, tab_mode, canon, bvh), 256, lds_bytes);
     return (e == hipSuccess && n > 0) ? n : 4;
 }
 
@@ -1764,6 +1799,7 @@ int validate_desc(const rtx_scene_desc* d) {
     if (d->n_nodes == 0 || !d->nodes) return fail(RTX_E_INVALID, "scene needs at least the world node");
     if (d->n_shapes && !d->shapes) return fail(RTX_E_INVALID, "shapes is NULL");
     if (d->n_materials == 0 || !d->materials) return fail(RTX_E_INVALID, "scene needs at least one material");
+    if (d->n_materials > kHitMaterialMask + 1u) return fail(RTX_E_INVALID, "too many materials (%u, at most %u)", d->n_materials, kHitMaterialMask + 1u);
     if (d->n_patterns && !d->patterns) return fail(RTX_E_INVALID, "patterns is NULL");
     if (d->n_shapes > kLinkIndexMask) return fail(RTX_E_INVALID, "too many shapes");
     for (uint32_t i = 0; i < d->n_shapes; ++i) {
@@ -1829,11 +1865,32 @@ void build_bvhs(std::vector<rtx_shape>& shapes, std::vector<rtx_node>& nodes, st
     }
 }
 
+// The 16-byte hit records of the (library-flagged) shapes: see HitRec.
+std::vector<HitRec> build_hitrecs(const std::vector<rtx_shape>& shapes) {
+    std::vector<HitRec> out(shapes.size());
+    for (size_t i = 0; i < shapes.size(); ++i) {
+        const rtx_shape& sh = shapes[i];
+        HitRec& h = out[i];
+        h.bits = (sh.material & kHitMaterialMask) | (sh.type << kHitTypeShift) | ((sh.flags & kShapeIdentity) ? kHitIdentity : 0u) |
+                 ((sh.flags & kShapeDiagonal) ? kHitDiagonal : 0u) | ((sh.flags & kShapeWorldNormal) ? kHitWorldNormal : 0u);
+        for (int k = 0; k < 3; ++k) h.n[k] = (sh.flags & kShapeWorldNormal) ? sh.normal[k] : 0.0f;
+    }
+    return out;
+}
+
 int check_camera(const rtx_camera* cam) {
     if (!cam) return fail(RTX_E_INVALID, "camera is NULL");
     if (cam->horizontal_size == 0 || cam->vertical_size == 0) return fail(RTX_E_INVALID, "empty canvas");
     if ((uint64_t)cam->horizontal_size * cam->vertical_size > kLinkIndexMask) return fail(RTX_E_INVALID, "canvas too large");
     return RTX_OK;
+}
+
+// Which tables go to LDS (k_trace_shade's TAB) and how many bytes that takes.
+void lds_plan(uint32_t n_shapes, uint32_t n_materials, uint32_t n_patterns, uint32_t* tab_mode, uint32_t* lds_bytes) {
+    const size_t small = sizeof(rtx_material) * n_materials + sizeof(rtx_pattern) * n_patterns + sizeof(HitRec) * n_shapes;
+    const size_t all = small + sizeof(rtx_shape) * n_shapes;
+    *tab_mode = all <= kLdsSceneBytes ? (uint32_t)kTabAll : (small <= kLdsSceneBytes ? (uint32_t)kTabHit : (uint32_t)kTabGlobal);
+    *lds_bytes = *tab_mode == (uint32_t)kTabAll ? (uint32_t)all : (*tab_mode == (uint32_t)kTabHit ? (uint32_t)small : 0u);
 }
 
 void fill_scene_params(const rtx_scene* s, Params& p, uint32_t depth) {
@@ -1850,11 +1907,8 @@ void fill_scene_params(const rtx_scene* s, Params& p, uint32_t depth) {
     p.n_shapes = s->n_shapes;
     p.n_materials = s->n_materials;
     p.n_patterns = s->n_patterns;
-    {
-        const size_t bytes = sizeof(rtx_shape) * s->n_shapes + sizeof(rtx_material) * s->n_materials +
-                             sizeof(rtx_pattern) * s->n_patterns;
-        p.lds_bytes = bytes <= kLdsSceneBytes ? (uint32_t)bytes : 0u;
-    }
+    p.hitrecs = s->d_hitrecs;
+    lds_plan(s->n_shapes, s->n_materials, s->n_patterns, &p.tab_mode, &p.lds_bytes);
     p.track_n1 = s->track_n1 ? 1u : 0u;
     p.depth = depth;
     std::memcpy(p.light_position, s->light_position, sizeof p.light_position);
@@ -1908,8 +1962,8 @@ int run_levels(rtx_scene* s, WorkSet& w, Params& p, uint32_t pixels, uint32_t le
     }();
     const int cz = (p.canon ? 1 : 0) + (p.has_bvh ? 2 : 0);
     if (s->resident_blocks[cz][0] == 0) {
-        s->resident_blocks[cz][0] = resident_blocks<false>(s, p.lds_bytes, p.canon != 0, p.has_bvh != 0);
-        s->resident_blocks[cz][1] = resident_blocks<true>(s, p.lds_bytes, p.canon != 0, p.has_bvh != 0);
+        s->resident_blocks[cz][0] = resident_blocks<false>(s, p.tab_mode, p.lds_bytes, p.canon != 0, p.has_bvh != 0);
+        s->resident_blocks[cz][1] = resident_blocks<true>(s, p.tab_mode, p.lds_bytes, p.canon != 0, p.has_bvh != 0);
     }
     auto grid_for = [&](uint64_t items, bool gen) {
         const uint32_t bpc = bpc_override > 0 ? (uint32_t)bpc_override : (uint32_t)s->resident_blocks[cz][gen ? 1 : 0];
@@ -2144,7 +2198,7 @@ int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_opts* opts, float
         for (int k = 0; k < 6; ++k) stats->shape_tests[k] = t.shape[k];
         stats->rows_rendered = plan.rows_local;
         stats->kernel_flags = (p.canon ? RTX_KERNEL_CANONICAL_W : 0u) | (p.has_bvh ? RTX_KERNEL_BVH : 0u) |
-                              (p.lds_bytes ? RTX_KERNEL_LDS_TABLES : 0u) | (s->track_n1 ? RTX_KERNEL_TRACK_N1 : 0u);
+                              (p.tab_mode == (uint32_t)kTabAll ? RTX_KERNEL_LDS_TABLES : 0u) | (p.tab_mode == (uint32_t)kTabHit ? RTX_KERNEL_LDS_HIT_RECORDS : 0u) | (s->track_n1 ? RTX_KERNEL_TRACK_N1 : 0u);
         HIP_TRY(hipEventElapsedTime(&stats->ms_total, s->ev_begin, s->ev_end));
         if (profile) {
             rc = collect_profile(s, stats);
@@ -2251,6 +2305,10 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out) {
     s->n_bvh_nodes = (uint32_t)bvh_nodes.size();
     s->n_bvh_tris = (uint32_t)bvh_tris.size();
     HIP_TRY_S(upload((void**)&s->d_shapes, shapes.data(), sizeof(rtx_shape) * shapes.size()));
+    {
+        const std::vector<HitRec> hitrecs = build_hitrecs(shapes);
+        HIP_TRY_S(upload((void**)&s->d_hitrecs, hitrecs.data(), sizeof(HitRec) * hitrecs.size()));
+    }
     HIP_TRY_S(upload((void**)&s->d_nodes, nodes.data(), sizeof(rtx_node) * nodes.size()));
     HIP_TRY_S(upload((void**)&s->d_nodes_linear, linear.data(), sizeof(rtx_node) * linear.size()));
     HIP_TRY_S(upload((void**)&s->d_bvh_nodes, bvh_nodes.data(), sizeof(rtx_bvh::Node) * bvh_nodes.size()));
@@ -2262,11 +2320,11 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out) {
     rc = bind_static_work(device, &s->ws_static);
     if (rc) return bail(rc);
     {  // occupancy of every kernel variant this scene can dispatch, so that no render call has to ask
-        const size_t bytes = sizeof(rtx_shape) * s->n_shapes + sizeof(rtx_material) * s->n_materials + sizeof(rtx_pattern) * s->n_patterns;
-        const uint32_t lds = bytes <= kLdsSceneBytes ? (uint32_t)bytes : 0u;
+        uint32_t tab = 0, lds = 0;
+        lds_plan(s->n_shapes, s->n_materials, s->n_patterns, &tab, &lds);
         for (int cz = 0; cz < 4; ++cz) {
-            s->resident_blocks[cz][0] = resident_blocks<false>(s, lds, (cz & 1) != 0, (cz & 2) != 0);
-            s->resident_blocks[cz][1] = resident_blocks<true>(s, lds, (cz & 1) != 0, (cz & 2) != 0);
+            s->resident_blocks[cz][0] = resident_blocks<false>(s, tab, lds, (cz & 1) != 0, (cz & 2) != 0);
+            s->resident_blocks[cz][1] = resident_blocks<true>(s, tab, lds, (cz & 1) != 0, (cz & 2) != 0);
         }
     }
     for (WorkSet& w : s->ws) {
@@ -2295,6 +2353,7 @@ void rtx_scene_destroy(rtx_scene* s) {
     if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
     if (s->d_canvas) (void)hipFree(s->d_canvas);
     if (s->d_shapes) (void)hipFree(s->d_shapes);
+    if (s->d_hitrecs) (void)hipFree(s->d_hitrecs);
     if (s->d_nodes) (void)hipFree(s->d_nodes);
     if (s->d_nodes_linear) (void)hipFree(s->d_nodes_linear);
     if (s->d_bvh_nodes) (void)hipFree(s->d_bvh_nodes);

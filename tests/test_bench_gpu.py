@@ -25,7 +25,7 @@ def test_single_gpu_line_names_the_north_star_frame():
     d, _ = _bench("--steps", "20", "--warmup", "2", "--no-cpu", "--no-configs")
     assert d["n_gpus"] == 1 and d["unit"] == "Mrays/s" and d["dtype"] == "f32" and d["vs_baseline"] is None
     assert "composite" in d["config"]["workload"] and "3840x2160" in d["config"]["workload"]
-    assert d["config"]["kernel_variant"] == {"canonical_w": True, "bvh": True, "lds_tables": False, "track_n1": True}
+    assert d["config"]["kernel_variant"] == {"canonical_w": True, "bvh": True, "lds_tables": False, "track_n1": True, "lds_hit_records": True}
     assert abs(d["value"] - d["config"]["rays_per_step"] / d["ms_per_step"] / 1e3) < 1e-6 * d["value"]
     r = d["roofline"]
     assert r["peak"] == 78.6 and r["launches"] > 0 and 0 < r["frac"] < 1 and r["events"]["bvh_box_tests"] > 0

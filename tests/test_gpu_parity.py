@@ -314,7 +314,8 @@ def test_teapot_matches_oracle_with_and_without_bvh():
     assert stats.kernel_flags & (K.KERNEL_CANONICAL_W | K.KERNEL_BVH) == K.KERNEL_CANONICAL_W | K.KERNEL_BVH
     assert stats_lin.kernel_flags & (K.KERNEL_CANONICAL_W | K.KERNEL_BVH) == K.KERNEL_CANONICAL_W
     assert stats_full.kernel_flags & (K.KERNEL_CANONICAL_W | K.KERNEL_BVH) == K.KERNEL_BVH
-    assert not stats.kernel_flags & K.KERNEL_LDS_TABLES  # 1568 shapes x 160 B do not fit the LDS budget
+    assert not stats.kernel_flags & K.KERNEL_LDS_TABLES  # 1568 shapes x 160 B do not fit the LDS budget ...
+    assert stats.kernel_flags & K.KERNEL_LDS_HIT_RECORDS  # ... their 16-byte hit records do
     scene.close()
 
 
@@ -399,6 +400,19 @@ def test_teapot_with_glass_and_mirror_matches_oracle():
     compare(gpu, ref, "teapot + glass + floor (BVH)")
     lin, _ = scene.render(cam, no_bvh=True)
     assert lin.tobytes() == gpu.tobytes()
+    assert stats.rays_total == counts.total
+    scene.close()
+
+
+def test_large_mesh_with_global_memory_tables_matches_oracle():
+    """6400 shapes: neither the shape records nor the hit records fit the LDS budget."""
+    world, cam, keep = rta.teapot_scene(_teapot_text(2), 64, 56)
+    ref, counts = o.render(cam, world)
+    scene = rta.Scene(world)
+    gpu, stats = scene.render(cam)
+    compare(gpu, ref, "teapot level 2")
+    K = rta.RtxStats
+    assert not stats.kernel_flags & (K.KERNEL_LDS_TABLES | K.KERNEL_LDS_HIT_RECORDS) and stats.kernel_flags & K.KERNEL_BVH
     assert stats.rays_total == counts.total
     scene.close()
 

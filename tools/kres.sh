@@ -18,8 +18,8 @@ for line in sys.stdin:
         cur[k] = v
 for r in rows:
     n = r["name"]
-    m = re.search(r"k_trace_shadeI((?:Lb\dE)+)", n)
-    names = ["GEN", "TRACK", "LDS", "C", "BVH", "STATS", "X6"]
-    tag = "trace " + " ".join(k + v for k, v in zip(names, re.findall(r"Lb(\d)E", m.group(1)))) if m else n[:40]
+    m = re.search(r"k_trace_shadeILi(\d)E((?:Lb\dE)+)", n)
+    names = ["GEN", "TRACK", "C", "BVH", "STATS", "X6"]
+    tag = "trace TAB" + m.group(1) + " " + " ".join(k + v for k, v in zip(names, re.findall(r"Lb(\d)E", m.group(2)))) if m else n[:40]
     print("%-36s VGPR %3s  spill %3s  scratch %5s  occ %s  SGPR %s" % (tag, r.get("VGPRs"), r.get("VGPRs Spill"), r.get("ScratchSize"), r.get("Occupancy"), r.get("TotalSGPRs")))
 '

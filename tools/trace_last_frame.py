@@ -13,9 +13,9 @@ def short(n):
     return (m.group(1) + (m.group(2) or "")) if m else n[:40]
 
 
-# a frame starts at a ray-generating launch (first template flag true); the last frame that does not
+# a frame starts at a ray-generating launch (template flag GEN, after TAB, true); the last frame that does not
 # count events (last template flag false) is the one a frame loop runs
-starts = [i for i, r in enumerate(rows) if re.search(r"k_trace_shade<true", r["Kernel_Name"])]
+starts = [i for i, r in enumerate(rows) if re.search(r"k_trace_shade<\d+, true", r["Kernel_Name"])]
 if not starts:
     sys.exit("no ray-generating launch found")
 plain = [i for i in starts if re.search(r"false>", rows[i]["Kernel_Name"])] or starts
