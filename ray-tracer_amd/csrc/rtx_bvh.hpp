@@ -285,21 +285,21 @@ struct Builder {
     }
 };
 
-// Build a BVH over shapes [first, first + count) (all triangles).  Appends the kLayouts threaded
-// layouts (equal size, one after the other: layout q starts at root + q * (nodes[root].skip - root))
-// to `nodes` and the leaf triangles to `tris`; returns the root of layout 0, or kNoLeaf if the run
-// cannot be bounded.
-inline uint32_t build_run(const rtx_shape* shapes, uint32_t first, uint32_t count, std::vector<Node>& nodes,
-                          std::vector<Tri>& tris) {
+// Build a BVH over the triangles `indices` of `shapes` (any subset, any order: the walk resolves ties on
+// the shape index).  Appends the kLayouts threaded layouts (equal size, one after the other: layout q
+// starts at root + q * (nodes[root].skip - root)) to `nodes` and the leaf triangles to `tris`; returns
+// the root of layout 0, or kNoLeaf if some triangle cannot be bounded.
+inline uint32_t build_list(const rtx_shape* shapes, const std::vector<uint32_t>& indices, std::vector<Node>& nodes,
+                           std::vector<Tri>& tris) {
     Builder b{tris, shapes, {}, {}};
-    b.prims.reserve(count);
-    for (uint32_t i = 0; i < count; ++i) {
-        const rtx_shape& s = shapes[first + i];
+    b.prims.reserve(indices.size());
+    for (uint32_t i : indices) {
+        const rtx_shape& s = shapes[i];
         // A triangle whose e0 is exactly zero can never be hit: det = dot(e0, ...) = 0 fails the
         // |det| < epsilon test (src/triangle.zig:36-37).  The OBJ fan emits one per polygon.
         if (s.e0[0] == 0.0f && s.e0[1] == 0.0f && s.e0[2] == 0.0f && s.e0[3] == 0.0f) continue;
         Prim p;
-        if (!bound_triangle(s, first + i, p)) return kNoLeaf;
+        if (!bound_triangle(s, i, p)) return kNoLeaf;
         b.prims.push_back(p);
     }
     const uint32_t root = (uint32_t)nodes.size();

@@ -726,7 +726,7 @@ __device__ __forceinline__ void traverse(V& v, T& tally, const Params& p, V4 o, 
         if (__ballot(active) == 0ull) continue;
         const uint32_t bvh_root = BVH ? node.reserved[0] : 0u;  // root + 1, 0 = no BVH
         const uint32_t first = node.first_shape;
-        const uint32_t last = first + (bvh_root ? node.reserved[1] : node.n_shapes);
+        const uint32_t last = first + (BVH ? node.reserved[1] : node.n_shapes);  // the rest sits in a tree (of this or a later node)
         for (uint32_t s = first; s < last; ++s) {
             tally.shapes(shapes[s].type, active);
             intersect_shape<C>(v, shapes[s], s, o, d, active);
@@ -1826,11 +1826,25 @@ int validate_desc(const rtx_scene_desc* d) {
     return RTX_OK;
 }
 
-// Library-side derived data: identity flags on the shapes and one BVH per long triangle run of a
-// gate (links in rtx_node.reserved: [0] = root + 1, [1] = shapes still tested linearly).
+// One triangle BVH: where it is walked and which shapes it holds (for rtx_bvh_selftest).
+struct BvhInfo {
+    uint32_t root, walk_node;
+    std::vector<uint32_t> shapes;
+};
+
+// Library-side derived data: identity flags on the shapes and the triangle BVHs.
+//
+// Nodes that share their gates form a class: a node with a box of its own (or the world) plus every
+// descendant reached without passing another box — a lane is active in all of them or in none
+// (OBJ groups: the bounded top group and its unbounded named sub-groups, src/obj_file.zig:45-62).
+// The trailing triangle runs of a class's nodes go into ONE tree, walked at the class's last node,
+// after every linearly tested shape of the class; the walk resolves ties on the shape index, so
+// mixing runs of different nodes keeps the insertion-order tie-break (Q13).
+// Links in rtx_node.reserved: [0] = root + 1 of the tree walked at this node (0: none), [1] = leading
+// shapes of the node tested linearly (all of them if none of its triangles is in a tree).
 // `linear` receives the gates without BVH links (rtx_opts.no_bvh).
 void build_bvhs(std::vector<rtx_shape>& shapes, std::vector<rtx_node>& nodes, std::vector<rtx_node>& linear,
-                std::vector<rtx_bvh::Node>& bvh_nodes, std::vector<rtx_bvh::Tri>& bvh_tris) {
+                std::vector<rtx_bvh::Node>& bvh_nodes, std::vector<rtx_bvh::Tri>& bvh_tris, std::vector<BvhInfo>* info = nullptr) {
     static const float kIdentity[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     for (rtx_shape& sh : shapes) {
         bool ident = true;
@@ -1848,20 +1862,39 @@ void build_bvhs(std::vector<rtx_shape>& shapes, std::vector<rtx_node>& nodes, st
             sh.flags |= kShapeWorldNormal;
         }
     }
-    for (rtx_node& n : nodes) n.reserved[0] = n.reserved[1] = 0;
-    linear = nodes;
     for (rtx_node& n : nodes) {
+        n.reserved[0] = 0;
+        n.reserved[1] = n.n_shapes;
+    }
+    linear = nodes;
+    // class of node i = its nearest ancestor-or-self with a box (the world node 0 otherwise)
+    const uint32_t nn = (uint32_t)nodes.size();
+    std::vector<uint32_t> cls(nn, 0u), open_nodes;
+    for (uint32_t i = 0; i < nn; ++i) {
+        while (!open_nodes.empty() && i >= nodes[open_nodes.back()].skip) open_nodes.pop_back();
+        cls[i] = (i == 0 || nodes[i].has_bounds || open_nodes.empty()) ? i : cls[open_nodes.back()];
+        open_nodes.push_back(i);
+    }
+    for (uint32_t c = 0; c < nn; ++c) {
+        if (cls[c] != c) continue;
         // rt_flatten emits a node's shapes in type order, so its triangles are the tail of its range.
         // The ABI does not require that order: only the maximal trailing run of triangles goes into
         // the tree, whatever precedes it (triangles included) is tested linearly, in insertion order.
-        uint32_t n_lin = n.n_shapes;
-        while (n_lin > 0 && shapes[n.first_shape + n_lin - 1].type == RTX_TRIANGLE) --n_lin;
-        const uint32_t n_tri = n.n_shapes - n_lin;
-        if (n_tri < rtx_bvh::kMinTris) continue;
-        const uint32_t root = rtx_bvh::build_run(shapes.data(), n.first_shape + n_lin, n_tri, bvh_nodes, bvh_tris);
+        std::vector<uint32_t> tris, members, n_lin;
+        for (uint32_t i = c; i < nn; ++i) {
+            if (cls[i] != c) continue;
+            uint32_t lin = nodes[i].n_shapes;
+            while (lin > 0 && shapes[nodes[i].first_shape + lin - 1].type == RTX_TRIANGLE) --lin;
+            members.push_back(i);
+            n_lin.push_back(lin);
+            for (uint32_t k = lin; k < nodes[i].n_shapes; ++k) tris.push_back(nodes[i].first_shape + k);
+        }
+        if (tris.size() < rtx_bvh::kMinTris) continue;
+        const uint32_t root = rtx_bvh::build_list(shapes.data(), tris, bvh_nodes, bvh_tris);
         if (root == rtx_bvh::kNoLeaf) continue;
-        n.reserved[0] = root + 1;
-        n.reserved[1] = n_lin;
+        for (size_t k = 0; k < members.size(); ++k) nodes[members[k]].reserved[1] = n_lin[k];
+        nodes[members.back()].reserved[0] = root + 1;
+        if (info) info->push_back(BvhInfo{root, members.back(), tris});
     }
 }
 
@@ -2444,14 +2477,20 @@ int rtx_bvh_selftest(const rtx_scene_desc* desc, const float* origins, const flo
     std::vector<rtx_node> nodes(desc->nodes, desc->nodes + desc->n_nodes), linear;
     std::vector<rtx_bvh::Node> bn;
     std::vector<rtx_bvh::Tri> bt;
-    build_bvhs(shapes, nodes, linear, bn, bt);
+    std::vector<BvhInfo> trees;
+    build_bvhs(shapes, nodes, linear, bn, bt, &trees);
     g_selftest_nodes = g_selftest_tris = 0;
     if (n_bvh_nodes) *n_bvh_nodes = (uint32_t)bn.size();
     if (n_bvh_tris) *n_bvh_tris = (uint32_t)bt.size();
     uint32_t bad = 0;
-    for (const rtx_node& g : nodes) {
-        if (!g.reserved[0]) continue;
-        const uint32_t root = g.reserved[0] - 1u, first_tri = g.first_shape + g.reserved[1], last_tri = g.first_shape + g.n_shapes;
+    for (const BvhInfo& tree : trees) {
+        const uint32_t root = tree.root;
+        if (nodes[tree.walk_node].reserved[0] != root + 1u) return fail(RTX_E_INVALID, "bvh %u: not linked at node %u", root, tree.walk_node);
+        const std::vector<uint32_t>& members = tree.shapes;  // ascending shape indices
+        auto slot_of = [&](uint32_t shape) -> long {
+            const auto it = std::lower_bound(members.begin(), members.end(), shape);
+            return (it != members.end() && *it == shape) ? (long)(it - members.begin()) : -1L;
+        };
         const uint32_t stride = bn[root].skip - root;
         if (bn[root].skip <= root || (size_t)root + (size_t)rtx_bvh::kLayouts * stride > bn.size())
             return fail(RTX_E_INVALID, "bvh %u: bad extent", root);
@@ -2460,7 +2499,7 @@ int rtx_bvh_selftest(const rtx_scene_desc* desc, const float* origins, const flo
         for (uint32_t q = 0; q < rtx_bvh::kLayouts; ++q) {
             const uint32_t lo = root + q * stride, end = lo + stride;
             if (bn[lo].skip != end) return fail(RTX_E_INVALID, "bvh %u layout %u: root skip %u != %u", root, q, bn[lo].skip, end);
-            std::vector<uint32_t> seen(last_tri - first_tri, 0u);
+            std::vector<uint32_t> seen(members.size(), 0u);
             for (uint32_t k = lo; k < end; ++k) {
                 const rtx_bvh::Node& nd = bn[k];
                 if (nd.skip <= k || nd.skip > end) return fail(RTX_E_INVALID, "bvh node %u: skip %u leaves [%u, %u)", k, nd.skip, lo, end);
@@ -2473,18 +2512,20 @@ int rtx_bvh_selftest(const rtx_scene_desc* desc, const float* origins, const flo
                 if ((size_t)t0 + cnt > bt.size()) return fail(RTX_E_INVALID, "bvh node %u: leaf out of range", k);
                 for (uint32_t t = t0; t < t0 + cnt; ++t) {
                     const rtx_bvh::Tri& tr = bt[t];
-                    if (tr.shape < first_tri || tr.shape >= last_tri) return fail(RTX_E_INVALID, "bvh leaf %u: foreign triangle %u", k, tr.shape);
-                    seen[tr.shape - first_tri]++;
+                    const long slot = slot_of(tr.shape);
+                    if (slot < 0) return fail(RTX_E_INVALID, "bvh leaf %u: foreign triangle %u", k, tr.shape);
+                    seen[(size_t)slot]++;
                     if (std::memcmp(tr.p0, shapes[tr.shape].p0, 12) || std::memcmp(tr.e0, shapes[tr.shape].e0, 12) ||
                         std::memcmp(tr.e1, shapes[tr.shape].e1, 12) || tr.flags != shapes[tr.shape].flags)
                         return fail(RTX_E_INVALID, "bvh leaf %u: triangle %u differs from its shape", k, tr.shape);
                 }
             }
-            for (uint32_t t = first_tri; t < last_tri; ++t) {
-                const rtx_shape& sh = shapes[t];
+            for (size_t m = 0; m < members.size(); ++m) {
+                const rtx_shape& sh = shapes[members[m]];
+                if (sh.type != RTX_TRIANGLE) return fail(RTX_E_INVALID, "bvh %u: shape %u is not a triangle", root, members[m]);
                 const bool degenerate = sh.e0[0] == 0.0f && sh.e0[1] == 0.0f && sh.e0[2] == 0.0f && sh.e0[3] == 0.0f;
-                if (seen[t - first_tri] != (degenerate ? 0u : 1u))
-                    return fail(RTX_E_INVALID, "layout %u: triangle %u sits in %u leaves", q, t, seen[t - first_tri]);
+                if (seen[m] != (degenerate ? 0u : 1u))
+                    return fail(RTX_E_INVALID, "layout %u: triangle %u sits in %u leaves", q, members[m], seen[m]);
             }
         }
         // rays: the traversal (closest hit, then the predecessor walk) against brute force
@@ -2507,7 +2548,7 @@ int rtx_bvh_selftest(const rtx_scene_desc* desc, const float* origins, const flo
             ClosestVisitor<true> ref;
             ref.init();
             PredVisitor pref{-INFINITY, kNone};
-            for (uint32_t t = first_tri; t < last_tri; ++t) {
+            for (uint32_t t : members) {
                 const rtx_shape& sh = shapes[t];
                 V4 ro = o, rd = d;
                 if (!(sh.flags & kShapeIdentity)) {

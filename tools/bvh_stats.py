@@ -32,6 +32,6 @@ nn, nt, bad = C.c_uint32(), C.c_uint32(), C.c_uint32()
 assert rta.lib().rtx_bvh_selftest(C.byref(flat.desc), rta.fptr(o), rta.fptr(d), len(o), C.byref(nn), C.byref(nt), C.byref(bad)) == 0
 boxes, tris = C.c_uint64(), C.c_uint64()
 rta.lib().rtx_bvh_selftest_work(C.byref(boxes), C.byref(tris))
-print("teapot level %s: %d shapes, %d BVH nodes, %d triangles in leaves; %d camera rays (4 sub-meshes each): "
+print("teapot level %s: %d shapes, %d BVH nodes, %d triangles in leaves; %d camera rays (one tree per gate class): "
       "%.1f box tests and %.2f triangle tests per ray, %d mismatches against brute force" % (
           level, flat.desc.n_shapes, nn.value, nt.value, len(o), boxes.value / len(o), tris.value / len(o), bad.value))
