@@ -38,8 +38,10 @@ void rt_ray_for_pixel(const rt_camera* c, uint32_t px, uint32_t py, rt_ray* out)
  * pub fn render(allocator, cam, world) !Canvas — src/camera.zig:84-105.
  * `canvas` is caller-owned, vertical_size*horizontal_size*3 f32, row-major (Canvas.pixels,
  * src/canvas.zig:15-28,52-54).  Like the reference, rows beyond 8*floor(vsize/8) stay
- * black (src/camera.zig:87-88).  Flattens the world, uploads it, renders on HIP device 0,
- * copies the canvas back; blocking.  `counts` may be NULL.
+ * black (src/camera.zig:87-88).  Flattens the world, uploads it, renders — fanned out over every
+ * visible HIP device like the reference's eight threads (rtx_multi_render; the environment variable
+ * RT_GPUS caps the number; one device: rtx_render on device 0) — and copies the canvas back;
+ * blocking.  `counts` may be NULL.
  */
 int rt_render(const rt_camera* cam, const rt_world* world, float* canvas, rt_ray_counts* counts);
 

@@ -234,6 +234,39 @@ int rtx_render_device_static(rtx_scene* scene, const rtx_camera* cam, const rtx_
 uint32_t rtx_static_max_width(void);
 
 /*
+ * ---- one frame on several GPUs of this process ------------------------------------------
+ *
+ * render() fans out and joins by itself (src/camera.zig:84-105: eight threads over static row
+ * bands); rtx_multi_* do the same over GPUs.  rtx_multi_create replicates the scene on `devices`
+ * (NULL / 0 = every visible device; an index may appear more than once, which is how a one-GPU box
+ * rehearses the path).  A render cuts the frame into n_devices * chunks_per_gpu interleaved sets of
+ * 16-row strips; one host thread per GPU takes sets from a shared counter until none is left
+ * (chunks_per_gpu = 1: each GPU renders one set; > 1: a GPU that finishes early takes another —
+ * dynamic stealing, where the reference's bands are static, src/camera.zig:88,99), renders each with
+ * the single-GPU pipeline and puts its rows in place:
+ *   rtx_multi_render         into caller-owned HOST canvases (f32 and / or u8, either may be NULL),
+ *                            every GPU copying over its own PCIe link;
+ *   rtx_multi_render_device  into canvases on the FIRST device of the list, peers copying over
+ *                            their own xGMI link (hipMemcpyPeerAsync) — the canvas exchange.
+ * Both block until the frame is complete.  The canvas equals rtx_render's bit for bit for any
+ * device list and chunk count.  `opts` as for rtx_render, except that strip_count / compact_rows
+ * must be zero (the strips are this call's) and profile is ignored; `stats` (may be NULL) sums the
+ * ray counts over all sets, ms_total is the wall time of the call.
+ */
+typedef struct rtx_multi rtx_multi;
+int rtx_multi_create(const rtx_scene_desc* desc, const int* devices, uint32_t n_devices, rtx_multi** out);
+void rtx_multi_destroy(rtx_multi* multi);
+uint32_t rtx_multi_device_count(const rtx_multi* multi);
+int rtx_multi_render(rtx_multi* multi, const rtx_camera* cam, const rtx_opts* opts, uint32_t chunks_per_gpu,
+                     float* rgb_out, uint8_t* rgb8_out, rtx_stats* stats);
+int rtx_multi_render_device(rtx_multi* multi, const rtx_camera* cam, const rtx_opts* opts, uint32_t chunks_per_gpu,
+                            void* d_rgb_out, void* d_rgb8_out, rtx_stats* stats);
+
+/* Global row of every local row a strip set renders (the compact_rows layout), host only: the
+ * partition arithmetic of the multi-GPU paths.  rows_out may be NULL to query the count. */
+int rtx_strip_row_map(const rtx_camera* cam, const rtx_opts* opts, uint32_t* rows_out, uint32_t cap, uint32_t* n_rows);
+
+/*
  * With opts->profile = 1 every kernel launch is bracketed by HIP events on the render
  * stream.  A call that passes `stats` reads them back itself; calls that do not (the
  * asynchronous frame loop) leave them pending, and this collects everything recorded since

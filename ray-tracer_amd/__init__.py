@@ -97,6 +97,12 @@ _SIGNATURES = [
     ("rtx_render_device", C.c_int, [C.c_void_p, P(RtxCamera), P(RtxOpts), C.c_void_p, C.c_void_p, C.c_void_p, P(RtxStats)]),
     ("rtx_render_device_static", C.c_int, [C.c_void_p, P(RtxCamera), P(RtxOpts), C.c_void_p, C.c_void_p, C.c_void_p]),
     ("rtx_static_max_width", u32, []),
+    ("rtx_multi_create", C.c_int, [P(RtxSceneDesc), P(C.c_int), u32, P(C.c_void_p)]),
+    ("rtx_multi_destroy", None, [C.c_void_p]),
+    ("rtx_multi_device_count", u32, [C.c_void_p]),
+    ("rtx_multi_render", C.c_int, [C.c_void_p, P(RtxCamera), P(RtxOpts), u32, P(f32), P(C.c_uint8), P(RtxStats)]),
+    ("rtx_multi_render_device", C.c_int, [C.c_void_p, P(RtxCamera), P(RtxOpts), u32, C.c_void_p, C.c_void_p, P(RtxStats)]),
+    ("rtx_strip_row_map", C.c_int, [P(RtxCamera), P(RtxOpts), P(u32), u32, P(u32)]),
     ("rtx_profile_collect", C.c_int, [C.c_void_p, P(RtxStats)]),
     ("rtx_color_at", C.c_int, [C.c_void_p, P(f32), P(f32), u32, u32, P(f32)]),
     ("rtx_bvh_selftest", C.c_int, [P(RtxSceneDesc), P(f32), P(f32), u32, P(u32), P(u32), P(u32)]),
@@ -382,6 +388,61 @@ class Scene:
         out = np.zeros((o.shape[0], 3), dtype=np.float32)
         _check(lib().rtx_color_at(self.handle, fptr(o), fptr(d), o.shape[0], depth, fptr(out)))
         return out
+
+
+class MultiScene:
+    """A scene replicated on several GPUs of this process (rtx_multi)."""
+
+    def __init__(self, world, devices=None):
+        flat = FlatScene(world)
+        h = C.c_void_p()
+        arr = (C.c_int * len(devices))(*devices) if devices else None
+        _check(lib().rtx_multi_create(C.byref(flat.desc), arr, len(devices) if devices else 0, C.byref(h)))
+        self.handle = h
+        self.n_devices = lib().rtx_multi_device_count(h)
+
+    def close(self):
+        if getattr(self, "handle", None) and lib is not None:
+            lib().rtx_multi_destroy(self.handle)
+            self.handle = None
+
+    __del__ = close
+
+    def render(self, cam, chunks_per_gpu=1, rows_quirk=True, depth=0, want_u8=True, want_stats=True, **kw):
+        """rtx_multi_render -> (f32 canvas [H, W, 3], u8 canvas or None, RtxStats or None), host arrays."""
+        rc = flatten_camera(cam) if isinstance(cam, st.Camera) else cam
+        opts = RtxOpts(depth=depth, rows_quirk=1 if rows_quirk else 0, batch_pixels=kw.get("batch_pixels", 0),
+                       no_bvh=1 if kw.get("no_bvh", False) else 0, full_w=1 if kw.get("full_w", False) else 0)
+        h, w = rc.vertical_size, rc.horizontal_size
+        canvas = np.full((h, w, 3), np.nan, dtype=np.float32)
+        canvas8 = np.full((h, w, 3), 77, dtype=np.uint8) if want_u8 else None
+        stats = RtxStats() if want_stats else None
+        _check(lib().rtx_multi_render(self.handle, C.byref(rc), C.byref(opts), chunks_per_gpu, fptr(canvas),
+                                      canvas8.ctypes.data_as(P(C.c_uint8)) if want_u8 else None,
+                                      C.byref(stats) if want_stats else None))
+        return canvas, canvas8, stats
+
+    def render_device(self, cam, d_rgb, d_rgb8=None, chunks_per_gpu=1, rows_quirk=True, want_stats=False):
+        """rtx_multi_render_device: canvases on the first device of the list (raw device pointers)."""
+        rc = flatten_camera(cam) if isinstance(cam, st.Camera) else cam
+        opts = RtxOpts(rows_quirk=1 if rows_quirk else 0)
+        stats = RtxStats() if want_stats else None
+        _check(lib().rtx_multi_render_device(self.handle, C.byref(rc), C.byref(opts), chunks_per_gpu, C.c_void_p(d_rgb),
+                                             C.c_void_p(d_rgb8) if d_rgb8 else None, C.byref(stats) if want_stats else None))
+        return stats
+
+
+def strip_row_map(cam, strips=None, rows_quirk=True):
+    """rtx_strip_row_map: the global row of every local row of a strip set (host only)."""
+    rc = flatten_camera(cam) if isinstance(cam, st.Camera) else cam
+    opts = RtxOpts(rows_quirk=1 if rows_quirk else 0)
+    if strips is not None:
+        opts.strip_rows, opts.strip_count, opts.strip_index = strips
+    n = u32()
+    _check(lib().rtx_strip_row_map(C.byref(rc), C.byref(opts), None, 0, C.byref(n)))
+    rows = (u32 * max(1, n.value))()
+    _check(lib().rtx_strip_row_map(C.byref(rc), C.byref(opts), rows, n.value, C.byref(n)))
+    return list(rows[: n.value])
 
 
 def rows_for(cam, strips=None, rows_quirk=True):

@@ -2259,6 +2259,9 @@ extern "C" {
 
 const char* rtx_last_error(void) { return g_err; }
 
+// For the library's other translation units (rtx_multi.hip): set this thread's message.  Not in rtx.h.
+__attribute__((visibility("default"))) void rtx_set_error(int code, const char* msg) { (void)fail(code, "%s", msg ? msg : ""); }
+
 int rtx_device_count(void) {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);

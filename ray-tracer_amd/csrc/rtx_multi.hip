@@ -1,0 +1,319 @@
+// rtx_multi.hip — one frame on several GPUs of one process, behind the C ABI (include/rtx.h).
+//
+// The reference's render() fans out and joins by itself: eight OS threads over static row bands
+// (src/camera.zig:84-105).  Here the callee does the same over GPUs: the scene is replicated on
+// every device (it is KBs to MBs), the frame is cut into interleaved sets of 16-row strips
+// ("chunks": chunk k of n holds the strips s with s % n == k, so every chunk sees the same mix of
+// cheap and expensive rows), one host thread per GPU takes chunks from a shared atomic counter until
+// none is left — with more chunks than GPUs that is dynamic stealing: a GPU that finishes early takes
+// the next chunk — renders each with the ordinary single-GPU pipeline (rtx_render_device, compact
+// rows) and puts the rows where they belong: straight into the caller's host canvas over that GPU's
+// own PCIe link, or into a canvas on the first device with peer copies (hipMemcpyPeerAsync: each
+// peer's own xGMI link to the root, no ring, no staging) — the exchange step of the path.  A single
+// process needs no collective library for peer-to-root copies; RCCL carries the same exchange where
+// ranks are processes (bench.py, ray-tracer_amd/tiling.py).
+//
+// Every pixel is produced by the same chain of f32 operations whatever the decomposition, so the
+// canvas equals the single-GPU canvas bit for bit (tests/test_gpu_parity.py).
+//
+// Host code only: this file launches no kernel of its own.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/rtx.h"
+
+extern "C" void rtx_set_error(int code, const char* msg);  // rtx_device.hip: the thread-local message of rtx_last_error()
+
+namespace {
+
+constexpr uint32_t kStripRows = 16;
+
+int fail(int code, const std::string& msg) {
+    rtx_set_error(code, msg.c_str());
+    return code;
+}
+
+struct Gpu {
+    int device = 0;
+    rtx_scene* scene = nullptr;
+    hipStream_t stream = nullptr;
+    float* d_rgb = nullptr;     // compact rows of one chunk
+    uint8_t* d_rgb8 = nullptr;
+    size_t cap_rows = 0, cap_width = 0;
+};
+
+}  // namespace
+
+struct rtx_multi {
+    std::vector<Gpu> gpus;
+};
+
+namespace {
+
+// Rows rendered at all (rows quirk, src/camera.zig:87-88).
+uint32_t rendered_rows(const rtx_camera* cam, const rtx_opts* o) {
+    return (o && o->rows_quirk) ? 8u * (cam->vertical_size / 8u) : cam->vertical_size;
+}
+
+int ensure_buffers(Gpu& g, size_t rows, size_t width) {
+    if (rows <= g.cap_rows && width <= g.cap_width) return RTX_OK;
+    if (g.d_rgb) (void)hipFree(g.d_rgb);
+    if (g.d_rgb8) (void)hipFree(g.d_rgb8);
+    g.d_rgb = nullptr;
+    g.d_rgb8 = nullptr;
+    g.cap_rows = g.cap_width = 0;
+    const size_t n = (rows ? rows : 1) * width * 3;
+    hipError_t e = hipMalloc(&g.d_rgb, n * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&g.d_rgb8, n);
+    if (e != hipSuccess) return fail(RTX_E_HIP, std::string("hipMalloc (multi-GPU chunk canvas): ") + hipGetErrorString(e));
+    g.cap_rows = rows;
+    g.cap_width = width;
+    return RTX_OK;
+}
+
+struct Job {
+    rtx_multi* m;
+    const rtx_camera* cam;
+    rtx_opts opts;          // the caller's options; strips are set per chunk
+    uint32_t n_chunks;
+    float* rgb_out;         // host (to_device == false) or device-0 (to_device == true) f32 canvas, may be NULL
+    uint8_t* rgb8_out;      // the same for the u8 canvas, may be NULL
+    bool to_device;
+    bool want_stats;
+    std::atomic<uint32_t> next{0};
+};
+
+struct Result {
+    int rc = RTX_OK;
+    std::string error;
+    rtx_stats stats{};
+    uint32_t chunks = 0;
+};
+
+void add_stats(rtx_stats& a, const rtx_stats& b) {
+    a.rays_primary += b.rays_primary;
+    a.rays_shadow += b.rays_shadow;
+    a.rays_secondary += b.rays_secondary;
+    a.nodes += b.nodes;
+    a.hits_patterned += b.hits_patterned;
+    a.hits_transparent += b.hits_transparent;
+    a.bvh_box_tests += b.bvh_box_tests;
+    a.bvh_triangle_tests += b.bvh_triangle_tests;
+    a.gate_tests += b.gate_tests;
+    for (int k = 0; k < 6; ++k) {
+        a.level_rays[k] += b.level_rays[k];
+        a.level_hits[k] += b.level_hits[k];
+        a.shape_tests[k] += b.shape_tests[k];
+    }
+    a.rows_rendered += b.rows_rendered;
+    a.kernel_flags |= b.kernel_flags;
+}
+
+// One GPU's host thread: take chunks until none is left.
+void worker(Job* job, size_t gi, Result* res) {
+    Gpu& g = job->m->gpus[gi];
+    const int root_device = job->m->gpus[0].device;
+    const uint32_t W = job->cam->horizontal_size;
+    const uint32_t total = rendered_rows(job->cam, &job->opts);
+    auto bail = [&](int rc, const std::string& what) {
+        res->rc = rc;
+        res->error = what;
+    };
+    hipError_t e = hipSetDevice(g.device);
+    if (e != hipSuccess) return bail(RTX_E_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    for (;;) {
+        const uint32_t k = job->next.fetch_add(1u);
+        if (k >= job->n_chunks) break;
+        rtx_opts o = job->opts;
+        o.strip_rows = kStripRows;
+        o.strip_count = job->n_chunks;
+        o.strip_index = k;
+        o.compact_rows = 1;
+        o.profile = 0;
+        uint32_t rows = 0;
+        int rc = rtx_rows_for(job->cam, &o, &rows);
+        if (rc) return bail(rc, rtx_last_error());
+        if (rows == 0) continue;  // more chunks than strips
+        rc = ensure_buffers(g, rows, W);
+        if (rc) return bail(rc, rtx_last_error());
+        rtx_stats st;
+        rc = rtx_render_device(g.scene, job->cam, &o, g.d_rgb, job->rgb8_out ? g.d_rgb8 : nullptr, g.stream, job->want_stats ? &st : nullptr);
+        if (rc) return bail(rc, rtx_last_error());
+        if (job->want_stats) add_stats(res->stats, st);
+        // The chunk's strips back to their rows: local strip j is global strip k + j * n_chunks.
+        uint32_t local = 0;
+        for (uint64_t s = k; s * kStripRows < total; s += job->n_chunks) {
+            const uint32_t y0 = (uint32_t)(s * kStripRows);
+            const uint32_t n = (total - y0 < kStripRows) ? total - y0 : kStripRows;
+            const size_t src = (size_t)local * W * 3, dst = (size_t)y0 * W * 3, count = (size_t)n * W * 3;
+            if (job->rgb_out) {
+                e = job->to_device ? hipMemcpyPeerAsync(job->rgb_out + dst, root_device, g.d_rgb + src, g.device, count * sizeof(float), g.stream)
+                                   : hipMemcpyAsync(job->rgb_out + dst, g.d_rgb + src, count * sizeof(float), hipMemcpyDeviceToHost, g.stream);
+                if (e != hipSuccess) return bail(RTX_E_HIP, std::string("canvas copy: ") + hipGetErrorString(e));
+            }
+            if (job->rgb8_out) {
+                e = job->to_device ? hipMemcpyPeerAsync(job->rgb8_out + dst, root_device, g.d_rgb8 + src, g.device, count, g.stream)
+                                   : hipMemcpyAsync(job->rgb8_out + dst, g.d_rgb8 + src, count, hipMemcpyDeviceToHost, g.stream);
+                if (e != hipSuccess) return bail(RTX_E_HIP, std::string("canvas copy: ") + hipGetErrorString(e));
+            }
+            local += n;
+        }
+        // The chunk buffers are reused by this GPU's next chunk: same stream, so the copies above
+        // are ordered before the next render.
+        res->chunks++;
+    }
+    e = hipStreamSynchronize(g.stream);
+    if (e != hipSuccess) return bail(RTX_E_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
+}
+
+int multi_render(rtx_multi* m, const rtx_camera* cam, const rtx_opts* opts, uint32_t chunks_per_gpu, float* rgb_out, uint8_t* rgb8_out,
+                 bool to_device, rtx_stats* stats) {
+    if (!m || m->gpus.empty()) return fail(RTX_E_INVALID, "multi-GPU scene is NULL");
+    if (!cam) return fail(RTX_E_INVALID, "camera is NULL");
+    if (!rgb_out && !rgb8_out) return fail(RTX_E_INVALID, "no output canvas");
+    if (opts && (opts->strip_count > 1 || opts->compact_rows)) return fail(RTX_E_INVALID, "strips are this call's to set: leave strip_count and compact_rows zero");
+    uint32_t probe = 0;
+    int rc = rtx_rows_for(cam, opts, &probe);  // validates the camera
+    if (rc) return rc;
+    const auto t0 = std::chrono::steady_clock::now();
+    Job job;
+    job.m = m;
+    job.cam = cam;
+    std::memset(&job.opts, 0, sizeof job.opts);
+    if (opts) job.opts = *opts;
+    const size_t n_gpus = m->gpus.size();
+    if (chunks_per_gpu == 0) chunks_per_gpu = 1;
+    if (chunks_per_gpu > 64) return fail(RTX_E_INVALID, "chunks_per_gpu at most 64");
+    job.n_chunks = (uint32_t)n_gpus * chunks_per_gpu;
+    job.rgb_out = rgb_out;
+    job.rgb8_out = rgb8_out;
+    job.to_device = to_device;
+    job.want_stats = stats != nullptr;
+    // Rows the reference never renders stay black (src/camera.zig:87-88, src/canvas.zig:23-25).
+    const uint32_t W = cam->horizontal_size, H = cam->vertical_size, total = rendered_rows(cam, &job.opts);
+    if (total < H) {
+        const size_t off = (size_t)total * W * 3, count = (size_t)(H - total) * W * 3;
+        if (to_device) {
+            hipError_t e = hipSetDevice(m->gpus[0].device);
+            if (e == hipSuccess && rgb_out) e = hipMemsetAsync(rgb_out + off, 0, count * sizeof(float), m->gpus[0].stream);
+            if (e == hipSuccess && rgb8_out) e = hipMemsetAsync(rgb8_out + off, 0, count, m->gpus[0].stream);
+            if (e != hipSuccess) return fail(RTX_E_HIP, std::string("hipMemsetAsync: ") + hipGetErrorString(e));
+        } else {
+            if (rgb_out) std::memset(rgb_out + off, 0, count * sizeof(float));
+            if (rgb8_out) std::memset(rgb8_out + off, 0, count);
+        }
+    }
+    std::vector<Result> results(n_gpus);
+    std::vector<std::thread> threads;
+    threads.reserve(n_gpus);
+    for (size_t g = 1; g < n_gpus; ++g) threads.emplace_back(worker, &job, g, &results[g]);
+    worker(&job, 0, &results[0]);  // the calling thread serves the first GPU
+    for (std::thread& t : threads) t.join();
+    for (const Result& r : results)
+        if (r.rc) return fail(r.rc, r.error);
+    if (stats) {
+        std::memset(stats, 0, sizeof *stats);
+        for (const Result& r : results) add_stats(*stats, r.stats);
+        stats->ms_total = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return RTX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rtx_multi_create(const rtx_scene_desc* desc, const int* devices, uint32_t n_devices, rtx_multi** out) {
+    if (!out) return fail(RTX_E_INVALID, "out is NULL");
+    *out = nullptr;
+    const int visible = rtx_device_count();
+    if (visible <= 0) return fail(RTX_E_NO_DEVICE, "no HIP device available (this library has no CPU path)");
+    std::vector<int> devs;
+    if (!devices || n_devices == 0) {
+        for (int d = 0; d < visible; ++d) devs.push_back(d);
+    } else {
+        devs.assign(devices, devices + n_devices);
+    }
+    if (devs.size() > 64) return fail(RTX_E_INVALID, "at most 64 devices");
+    rtx_multi* m = new (std::nothrow) rtx_multi();
+    if (!m) return fail(RTX_E_NOMEM, "out of host memory");
+    m->gpus.resize(devs.size());
+    for (size_t i = 0; i < devs.size(); ++i) {
+        Gpu& g = m->gpus[i];
+        g.device = devs[i];
+        int rc = rtx_scene_create(desc, g.device, &g.scene);  // validates the device index and the descriptor
+        hipError_t e = hipSuccess;
+        if (rc == RTX_OK) {
+            e = hipSetDevice(g.device);
+            if (e == hipSuccess) e = hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking);
+            if (e != hipSuccess) rc = fail(RTX_E_HIP, std::string("hipStreamCreateWithFlags: ") + hipGetErrorString(e));
+        }
+        if (rc) {
+            const std::string msg = rtx_last_error();
+            rtx_multi_destroy(m);
+            return fail(rc, msg);
+        }
+    }
+    *out = m;
+    return RTX_OK;
+}
+
+void rtx_multi_destroy(rtx_multi* m) {
+    if (!m) return;
+    for (Gpu& g : m->gpus) {
+        (void)hipSetDevice(g.device);
+        if (g.stream) {
+            (void)hipStreamSynchronize(g.stream);
+            (void)hipStreamDestroy(g.stream);
+        }
+        if (g.d_rgb) (void)hipFree(g.d_rgb);
+        if (g.d_rgb8) (void)hipFree(g.d_rgb8);
+        if (g.scene) rtx_scene_destroy(g.scene);
+    }
+    delete m;
+}
+
+uint32_t rtx_multi_device_count(const rtx_multi* m) { return m ? (uint32_t)m->gpus.size() : 0u; }
+
+int rtx_multi_render(rtx_multi* m, const rtx_camera* cam, const rtx_opts* opts, uint32_t chunks_per_gpu, float* rgb_out,
+                     uint8_t* rgb8_out, rtx_stats* stats) {
+    return multi_render(m, cam, opts, chunks_per_gpu, rgb_out, rgb8_out, false, stats);
+}
+
+int rtx_multi_render_device(rtx_multi* m, const rtx_camera* cam, const rtx_opts* opts, uint32_t chunks_per_gpu, void* d_rgb_out,
+                            void* d_rgb8_out, rtx_stats* stats) {
+    return multi_render(m, cam, opts, chunks_per_gpu, (float*)d_rgb_out, (uint8_t*)d_rgb8_out, true, stats);
+}
+
+int rtx_strip_row_map(const rtx_camera* cam, const rtx_opts* opts, uint32_t* rows_out, uint32_t cap, uint32_t* n_rows) {
+    uint32_t rows = 0;
+    int rc = rtx_rows_for(cam, opts, &rows);
+    if (rc) return rc;
+    if (!n_rows) return fail(RTX_E_INVALID, "n_rows is NULL");
+    *n_rows = rows;
+    if (!rows_out) return RTX_OK;
+    if (cap < rows) return fail(RTX_E_INVALID, "row map needs " + std::to_string(rows) + " entries");
+    const uint32_t total = rendered_rows(cam, opts);
+    const uint32_t count = (opts && opts->strip_count > 1) ? opts->strip_count : 1u;
+    const uint32_t strip = (opts && opts->strip_rows) ? opts->strip_rows : 8u;
+    const uint32_t index = count > 1 ? opts->strip_index : 0u;
+    uint32_t local = 0;
+    if (count == 1) {
+        for (uint32_t y = 0; y < total; ++y) rows_out[local++] = y;
+        return RTX_OK;
+    }
+    for (uint64_t s = index; s * strip < total; s += count)
+        for (uint32_t y = (uint32_t)(s * strip); y < total && y < (uint32_t)((s + 1) * strip); ++y) rows_out[local++] = y;
+    return RTX_OK;
+}
+
+}  // extern "C"

@@ -7,6 +7,7 @@
 // Compile with -ffp-contract=off, no fast-math.
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -523,18 +524,36 @@ int rt_render(const rt_camera* cam, const rt_world* world, float* canvas, rt_ray
     rt_flat_scene* flat = nullptr;
     int rc = rt_flatten(world, &flat);
     if (rc) return rc;
-    rtx_scene* scene = nullptr;
-    rc = rtx_scene_create(rt_flat_desc(flat), 0, &scene);
-    rt_flat_free(flat);
-    if (rc) return rc;
     rtx_camera rc_cam;
     rt_flatten_camera(cam, &rc_cam);
     rtx_opts opts;
     std::memset(&opts, 0, sizeof opts);
     opts.rows_quirk = 1;  // src/camera.zig:87-88
     rtx_stats stats;
-    rc = rtx_render(scene, &rc_cam, &opts, canvas, &stats);
-    rtx_scene_destroy(scene);
+    // The callee fans out and joins, like the reference's eight threads (src/camera.zig:87-101): over
+    // every visible GPU (RT_GPUS caps the number), one host thread each (rtx_multi_*).
+    int gpus = rtx_device_count();
+    if (const char* cap = std::getenv("RT_GPUS")) {
+        const int want = std::atoi(cap);
+        if (want > 0 && want < gpus) gpus = want;
+    }
+    if (gpus > 1) {
+        rtx_multi* multi = nullptr;
+        std::vector<int> devices;
+        for (int d = 0; d < gpus; ++d) devices.push_back(d);
+        rc = rtx_multi_create(rt_flat_desc(flat), devices.data(), (uint32_t)devices.size(), &multi);
+        rt_flat_free(flat);
+        if (rc) return rc;
+        rc = rtx_multi_render(multi, &rc_cam, &opts, 1, canvas, nullptr, &stats);
+        rtx_multi_destroy(multi);
+    } else {
+        rtx_scene* scene = nullptr;
+        rc = rtx_scene_create(rt_flat_desc(flat), 0, &scene);
+        rt_flat_free(flat);
+        if (rc) return rc;
+        rc = rtx_render(scene, &rc_cam, &opts, canvas, &stats);
+        rtx_scene_destroy(scene);
+    }
     if (rc == 0 && counts) {
         counts->primary = stats.rays_primary;
         counts->shadow = stats.rays_shadow;

@@ -671,3 +671,45 @@ def test_by_value_rt_color_at_and_camera_init():
     assert rta.lib().rt_color_at(C.byref(s.world), rays, 48, rta.fptr(out)) == 0
     ref = np.stack([o.color_at(s.world, list(rays[k].origin), list(rays[k].direction)) for k in range(48)])
     compare(out[None], ref[None], "rt_color_at")
+
+
+# ---- several GPUs behind the C ABI (rtx_multi_*): one-GPU boxes rehearse with device 0 listed more than once ----
+
+@pytest.mark.parametrize("devices,chunks", [([0], 1), ([0, 0], 1), ([0, 0, 0], 2), ([0], 5)])
+def test_multi_gpu_render_equals_the_single_gpu_canvas(devices, chunks):
+    import torch
+
+    s = rta.Sample("glass_spheres", 250, 190)  # ragged width, 184 rows rendered: the last strip is short
+    single = rta.Scene(s.world)
+    want, want_stats = single.render(s.camera)
+    single.close()
+    multi = rta.MultiScene(s.world, devices=devices)
+    assert multi.n_devices == len(devices)
+    got, got8, st = multi.render(s.camera, chunks_per_gpu=chunks)
+    assert got.tobytes() == want.tobytes()
+    assert np.array_equal(got8, rta.to_ppm_bytes(want))
+    assert (st.rays_primary, st.rays_shadow, st.rays_secondary) == (want_stats.rays_primary, want_stats.rays_shadow, want_stats.rays_secondary)
+    assert st.rows_rendered == 184 and list(st.level_rays) == list(want_stats.level_rays)
+    # the same into canvases on the first device (peer copies)
+    rgb = torch.full((190, 250, 3), 7.0, dtype=torch.float32, device="cuda:0")
+    rgb8 = torch.full((190, 250, 3), 9, dtype=torch.uint8, device="cuda:0")
+    multi.render_device(s.camera, rgb.data_ptr(), rgb8.data_ptr(), chunks_per_gpu=chunks)
+    torch.cuda.synchronize()
+    assert rgb.cpu().numpy().tobytes() == want.tobytes() and np.array_equal(rgb8.cpu().numpy(), rta.to_ppm_bytes(want))
+    full, _, _ = multi.render(s.camera, chunks_per_gpu=chunks, rows_quirk=False, want_u8=False, want_stats=False)
+    ref_full, _ = o.render(s.camera, s.world, rows_quirk=False)
+    compare(full, ref_full, "multi, all rows")
+    multi.close()
+
+
+def test_multi_gpu_render_of_the_mesh_composite_and_errors():
+    world, cam, keep = rta.composite_scene(_teapot_text(), 640, 360)
+    single = rta.Scene(world)
+    want, _ = single.render(cam)
+    single.close()
+    multi = rta.MultiScene(world, devices=[0, 0])
+    got, _, _ = multi.render(cam, chunks_per_gpu=3, want_u8=False, want_stats=False)
+    assert got.tobytes() == want.tobytes()
+    multi.close()
+    with pytest.raises(rta.RtxError):
+        rta.MultiScene(world, devices=[0, 99])

@@ -110,3 +110,21 @@ def _render_worker(rank, world, port, name, width, height, strip, steps, ok):
 @pytest.mark.parametrize("world,name,width,height,strip", [(2, "glass_spheres", 64, 48, 16), (3, "sphere_world", 50, 70, 8)])
 def test_strip_exchange_of_rendered_frames(world, name, width, height, strip):
     assert _run(_render_worker, world, name, width, height, strip, 5) == 1
+
+
+@pytest.mark.parametrize("height,gpus,chunks", [(1080, 2, 1), (2160, 8, 1), (2160, 8, 4), (70, 3, 2), (16, 4, 3), (500, 1, 1)])
+def test_multi_gpu_partition_through_the_c_abi(height, gpus, chunks):
+    """rtx_multi_render cuts a frame into gpus * chunks interleaved strip sets; rtx_strip_row_map is the
+    arithmetic it places rows with (host code, no GPU): every rendered row belongs to exactly one set,
+    in the compact order the renderer writes, and agrees with the multi-process path's tiling.py."""
+    cam = rta.Sample("cone", 40, height).camera
+    n = gpus * chunks
+    seen = []
+    for k in range(n):
+        rows = rta.strip_row_map(cam, strips=(16, n, k))
+        assert rows == tiling.rows_of_rank(height, 16, n, k)
+        assert len(rows) == rta.rows_for(cam, strips=(16, n, k))
+        seen += rows
+    assert sorted(seen) == list(range(8 * (height // 8)))
+    assert rta.strip_row_map(cam) == list(range(8 * (height // 8)))
+    assert rta.strip_row_map(cam, rows_quirk=False) == list(range(height))
