@@ -150,8 +150,17 @@ typedef struct rtx_opts {
                               streams, so one batch's kernels fill the tails of the other's: 1 or 2;
                               0 = auto (2 for multi-level frames of >= 4 Mpx, where it cuts the frame time
                               by 13-17 %; 1 otherwise: the fork/join costs more than it wins on short frames) */
-    uint32_t reserved;
+    uint32_t containers;   /* RTX_CONTAINERS_*: how prepareComputationsForRefraction's container walk compares entries */
 } rtx_opts;
+
+/* rtx_opts.containers.  V1 (default) is the reference as written: std.meta.eql on whole Intersections,
+ * t included (src/intersection.zig:104,128), so an exit never removes its entry and n1 is the index of
+ * the entry just before the hit.  BOOK compares shapes only — the algorithm of the book the reference
+ * follows, and what the reference's shipped refractive images (samples/images/glass_spheres.ppm, the
+ * glass cylinder of cylinder_world.ppm) were rendered with by an older revision: an entry
+ * toggles its shape in and out of the list.  BOOK exists to report against those images; it runs the
+ * plainest kernel variants. */
+enum { RTX_CONTAINERS_V1 = 0, RTX_CONTAINERS_BOOK = 1 };
 
 typedef struct rtx_stats {
     uint64_t rays_primary;   /* colorAtInternal calls at the root (src/world.zig:85) */

@@ -197,6 +197,7 @@ struct Params {
     uint32_t canon;     // this frame runs the canonical-w kernels (ray records are 32 bytes)
     uint32_t has_bvh;   // some gate node of `nodes` carries a triangle BVH
     uint32_t finite_schlick;  // every refractive index is finite and > 0 (schlick() is finite)
+    uint32_t book;            // rtx_opts.containers == RTX_CONTAINERS_BOOK (and the scene tracks n1)
     uint32_t depth;
     float light_position[4];
     float light_intensity[3];
@@ -328,14 +329,29 @@ struct Closest {
     uint32_t pred_idx;
 };
 
-template <bool TRACK>
+// BOOK (rtx_opts.containers = RTX_CONTAINERS_BOOK): the container walk compares shapes only, as the
+// book the reference follows does and as the reference's shipped refractive images were rendered
+// (SURVEY Q7).  Every entry before the hit in the sorted list has t < 0 (the hit is the first t >= 0),
+// and an entry toggles its shape in and out of the container list, so at the hit the list holds the
+// shapes with an ODD number of negative roots, ordered by their largest negative root (ties: later
+// insertion last).  n1 is the index of the last of them (else 1); the hit then toggles its own shape:
+// if it was absent it is appended (n2 = its own index), if it was present it is removed (n2 = the new
+// last: the runner-up if the hit shape was last, n1 otherwise).  So BOOK tracks the best TWO odd-parity
+// shapes (pred_*, pred2_*) and whether the hit shape itself is one (hit_contained).
+template <bool TRACK, bool BOOK = false>
 struct ClosestVisitor {
     Closest c;
+    float pred2_t;
+    uint32_t pred2_idx;
+    bool hit_contained;
     RTX_HD void init() {
         c.t = INFINITY;  // "none yet" carries the range end the BVH walk culls against (t_hi / t_lo)
         c.idx = kNone;
         c.pred_t = -INFINITY;
         c.pred_idx = kNone;
+        pred2_t = -INFINITY;
+        pred2_idx = kNone;
+        hit_contained = false;
     }
     // Ties go to the lowest insertion index for the hit and to the highest for the predecessor.
     // The world/group walk offers shapes in insertion order (ORDERED): a strict compare is
@@ -348,6 +364,7 @@ struct ClosestVisitor {
         const bool better = (t >= 0.0f) & ((c.idx == kNone) | (t < c.t) | (!ORDERED & (t == c.t) & (s < c.idx)));
         c.t = better ? t : c.t;
         c.idx = better ? s : c.idx;
+        if (BOOK) hit_contained = better ? false : hit_contained;  // book_shape() of the same shape follows and decides
     }
     template <bool ORDERED>
     RTX_HD void pred(float t, uint32_t s) {
@@ -357,7 +374,19 @@ struct ClosestVisitor {
         c.pred_t = better ? t : c.pred_t;
         c.pred_idx = better ? s : c.pred_idx;
     }
+    // BOOK: shape s has been offered whole; `odd`: an odd number of its roots is negative, `tm` the
+    // largest of them.  Shapes arrive in insertion order, so a tie in tm goes to the newcomer.
+    RTX_HD void book_shape(uint32_t s, bool odd, float tm) {
+        const bool first = odd & ((c.pred_idx == kNone) | (tm >= c.pred_t));
+        const bool second = odd & !first & ((pred2_idx == kNone) | (tm >= pred2_t));
+        pred2_t = first ? c.pred_t : (second ? tm : pred2_t);
+        pred2_idx = first ? c.pred_idx : (second ? s : pred2_idx);
+        c.pred_t = first ? tm : c.pred_t;
+        c.pred_idx = first ? s : c.pred_idx;
+        hit_contained = (c.idx == s) ? odd : hit_contained;
+    }
     static constexpr bool kTrack = TRACK;
+    static constexpr bool kBook = BOOK;
     RTX_HD void visited_node() {}     // statistics hooks of the BVH walk (rtx_bvh_selftest counts with them)
     RTX_HD void tested_triangle() {}
     // The BVH walk of the closest-hit pass looks ahead of the origin only: a predecessor among
@@ -372,14 +401,24 @@ struct ClosestVisitor {
 
 // The n1 predecessor among BVH triangles: the largest t < 0, ties to the highest insertion
 // index, merged into what the insertion-ordered walk found among the other shapes.
-struct PredVisitor {
+// BOOK: a triangle has one root, so a negative root is an odd count: the walk keeps the best two
+// (see ClosestVisitor) and culls against the runner-up.
+template <bool BOOK = false>
+struct PredVisitorT {
     float pred_t;
     uint32_t pred_idx;
+    float pred2_t = -INFINITY;
+    uint32_t pred2_idx = kNone;
     template <bool ORDERED>
     RTX_HD void hit(float, uint32_t) {}
     template <bool ORDERED>
     RTX_HD void pred(float t, uint32_t s) {
         const bool better = (t < 0.0f) & ((pred_idx == kNone) | (t > pred_t) | ((t == pred_t) & (s > pred_idx)));
+        if (BOOK) {
+            const bool second = (t < 0.0f) & !better & ((pred2_idx == kNone) | (t > pred2_t) | ((t == pred2_t) & (s > pred2_idx)));
+            pred2_t = better ? pred_t : (second ? t : pred2_t);
+            pred2_idx = better ? pred_idx : (second ? s : pred2_idx);
+        }
         pred_t = better ? t : pred_t;
         pred_idx = better ? s : pred_idx;
     }
@@ -387,9 +426,10 @@ struct PredVisitor {
     RTX_HD void visited_node() {}
     RTX_HD void tested_triangle() {}
     RTX_HD bool done() const { return false; }
-    RTX_HD float t_lo() const { return pred_t; }  // -inf while there is none (ClosestVisitor::init)
+    RTX_HD float t_lo() const { return BOOK ? pred2_t : pred_t; }  // -inf while there is none (ClosestVisitor::init)
     RTX_HD float t_hi() const { return 0.0f; }
 };
+using PredVisitor = PredVisitorT<false>;
 
 // isShadowed (src/world.zig:97-120): the nearest t >= 0 is < distance  <=>  some root lies
 // in [0, distance).
@@ -401,6 +441,7 @@ struct ShadowVisitor {
     template <bool ORDERED>
     __device__ __forceinline__ void pred(float, uint32_t) {}
     static constexpr bool kTrack = false;
+    static constexpr bool kBook = false;
     static constexpr bool kBvhPred = false;
     __device__ __forceinline__ void visited_node() {}
     __device__ __forceinline__ void tested_triangle() {}
@@ -444,12 +485,21 @@ __device__ __forceinline__ bool bounds_hit(const RT_CONST rtx_node& n, V4 o, V4 
 template <class V>
 __device__ __forceinline__ void offer1(V& v, uint32_t s, bool n1_visible, float t) {
     v.template hit<true>(t, s);
+    if constexpr (V::kBook) {
+        v.book_shape(s, n1_visible & (t < 0.0f), t);
+        return;
+    }
     if (V::kTrack && n1_visible) v.template pred<true>(t, s);
 }
 template <class V>
 __device__ __forceinline__ void offer2(V& v, uint32_t s, bool n1_visible, float t0, float t1) {
     v.template hit<true>(t0, s);
     v.template hit<true>(t1, s);
+    if constexpr (V::kBook) {  // exactly one negative root: that one is the largest
+        const bool n0 = t0 < 0.0f, n1 = t1 < 0.0f;
+        v.book_shape(s, n1_visible & (n0 != n1), n0 ? t0 : t1);
+        return;
+    }
     if (V::kTrack && n1_visible) {  // wave-uniform flag; equal roots cancel each other: offer NaN (never a predecessor) then
         const bool distinct = t0 != t1;
         v.template pred<true>(distinct ? t0 : NAN, s);
@@ -462,6 +512,18 @@ template <class V>
 __device__ __forceinline__ void offer_roots(V& v, uint32_t s, bool n1_visible, const float* t) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) v.template hit<true>(t[i], s);
+    if constexpr (V::kBook) {
+        uint32_t negatives = 0;
+        float tm = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool neg_root = t[i] < 0.0f;  // false for an empty slot (NaN)
+            negatives += neg_root ? 1u : 0u;
+            tm = (neg_root & (t[i] > tm)) ? t[i] : tm;
+        }
+        v.book_shape(s, n1_visible & ((negatives & 1u) != 0u), tm);
+        return;
+    }
     if (V::kTrack && n1_visible) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -736,8 +798,8 @@ __device__ __forceinline__ void traverse(V& v, T& tally, const Params& p, V4 o, 
 }
 
 // The gates again, for the BVH triangles only: the predecessor walk of the lanes in `lane_on`.
-template <bool C, class T>
-__device__ __forceinline__ void traverse_pred(PredVisitor& v, T& tally, const Params& p, V4 o, V4 d, bool lane_on) {
+template <bool C, class PV, class T>
+__device__ __forceinline__ void traverse_pred(PV& v, T& tally, const Params& p, V4 o, V4 d, bool lane_on) {
     uint32_t parked_until = lane_on ? 0u : kNone;
     const RT_CONST rtx_node* nodes = as_const(p.nodes);
     for (uint32_t n = 0; n < p.n_nodes; ++n) {
@@ -1075,7 +1137,7 @@ constexpr int kTabHit = 2;     // hit records, materials, patterns; the 160-byte
 #ifndef RTX_WAVES_PER_EU_NOBVH
 #define RTX_WAVES_PER_EU_NOBVH 6
 #endif
-template <int TAB, bool GEN, bool TRACK, bool C, bool BVH, bool STATS>
+template <int TAB, bool GEN, bool TRACK, bool C, bool BVH, bool STATS, bool BOOK = false>
 __global__ __launch_bounds__(256)
 __attribute__((amdgpu_waves_per_eu((BVH || !C) ? RTX_WAVES_PER_EU : RTX_WAVES_PER_EU_NOBVH,
                                    (BVH || !C) ? RTX_WAVES_PER_EU : RTX_WAVES_PER_EU_NOBVH))) void k_trace_shade(const Params p, const uint32_t level) {
@@ -1211,7 +1273,8 @@ __attribute__((amdgpu_waves_per_eu((BVH || !C) ? RTX_WAVES_PER_EU : RTX_WAVES_PE
 
         DIAG_PHASE(0);  // ray fetch / generation
         // colorAtInternal: world.intersect + hit (src/world.zig:85-95)
-        ClosestVisitor<TRACK> cv;
+        static_assert(!BOOK || TRACK, "the book container walk is a form of n1 tracking");
+        ClosestVisitor<TRACK, BOOK> cv;
         cv.init();
         traverse<C, BVH>(cv, tally, p, o, d, on);
         const bool is_hit = on && cv.c.idx != kNone;
@@ -1220,11 +1283,15 @@ __attribute__((amdgpu_waves_per_eu((BVH || !C) ? RTX_WAVES_PER_EU : RTX_WAVES_PE
             // src/intersection.zig:165): only those lanes look for a predecessor among the meshes.
             const bool need = is_hit && tab.materials[tab.hit[cv.c.idx].bits & kHitMaterialMask].transparency != 0.0f;
             if (__ballot(need) != 0ull) {
-                PredVisitor pv{cv.c.pred_t, cv.c.pred_idx};
+                PredVisitorT<BOOK> pv{cv.c.pred_t, cv.c.pred_idx, cv.pred2_t, cv.pred2_idx};
                 traverse_pred<C>(pv, tally, p, o, d, need);
                 if (need) {
                     cv.c.pred_t = pv.pred_t;
                     cv.c.pred_idx = pv.pred_idx;
+                    if (BOOK) {
+                        cv.pred2_t = pv.pred2_t;
+                        cv.pred2_idx = pv.pred2_idx;
+                    }
                 }
             }
         }
@@ -1255,6 +1322,13 @@ __attribute__((amdgpu_waves_per_eu((BVH || !C) ? RTX_WAVES_PER_EU : RTX_WAVES_PE
             // n1 / n2 (src/intersection.zig:92-159, see Closest above)
             if (TRACK && cv.c.pred_idx != kNone) n1 = tab.materials[tab.hit[cv.c.pred_idx].bits & kHitMaterialMask].refractive_index;
             n2 = tab.materials[hr.bits & kHitMaterialMask].refractive_index;
+            if (BOOK && cv.hit_contained) {
+                // the hit leaves its own shape: what remains is the runner-up if the shape was the last
+                // container, the unchanged last one otherwise, 1.0 if nothing is left
+                n2 = n1;
+                if (cv.c.pred_idx == cv.c.idx)
+                    n2 = cv.pred2_idx != kNone ? tab.materials[tab.hit[cv.pred2_idx].bits & kHitMaterialMask].refractive_index : 1.0f;
+            }
             over_point = add(point, muls(normal, p.over_eps));
             const V4 lp = v4(p.light_position[0], p.light_position[1], p.light_position[2], p.light_position[3]);
             const V4 to_light = sub(lp, over_point);
@@ -1769,6 +1843,12 @@ template <int TAB, bool... Flags, class... Rest>
 TraceKernel pick_kernel(bool f, Rest... rest) {
     return f ? pick_kernel<TAB, Flags..., true>(rest...) : pick_kernel<TAB, Flags..., false>(rest...);
 }
+// Book-mode kernels exist in the plainest form only (tables in global memory, four-lane arithmetic, no
+// event tallies): the mode reports against the reference's stale images, it is not a fast path.
+template <bool GEN>
+TraceKernel book_kernel(bool bvh) {
+    return bvh ? k_trace_shade<kTabGlobal, GEN, true, false, true, false, true> : k_trace_shade<kTabGlobal, GEN, true, false, false, false, true>;
+}
 template <bool GEN>
 TraceKernel trace_kernel(bool track, uint32_t tab, bool canon, bool bvh, bool stats = false) {
     if (tab == (uint32_t)kTabAll) return pick_kernel<kTabAll, GEN>(track, canon, bvh, stats);
@@ -1783,7 +1863,8 @@ void launch_trace(const rtx_scene* s, const Params& p, uint32_t level, uint32_t 
     // provided the reflectance is finite (0 * R must be 0): s->finite_schlick.  The last level
     // holds the most rays and runs the kernel without predecessor tracking.
     const bool track = s->track_n1 && !(level == p.depth && s->finite_schlick);
-    hipLaunchKernelGGL(trace_kernel<GEN>(track, p.tab_mode, p.canon != 0, p.has_bvh != 0, stats), dim3(blocks), dim3(256), p.lds_bytes, st, p, level);
+    const TraceKernel k = (p.book && track) ? book_kernel<GEN>(p.has_bvh != 0) : trace_kernel<GEN>(track, p.tab_mode, p.canon != 0, p.has_bvh != 0, stats);
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(256), p.lds_bytes, st, p, level);
 }
 
 // Resident 256-thread blocks per CU of a variant (registers and LDS decide).
@@ -2133,6 +2214,14 @@ int render_impl(rtx_scene* s, const rtx_camera* cam, const rtx_opts* opts, float
         const bool cam_canon = ci[12] == 0.0f && ci[13] == 0.0f && ci[14] == 0.0f && ci[15] == 1.0f;
         static const bool off = getenv("RTX_NO_CANON") != nullptr;  // A/B switch for experiments
         p.canon = (s->canon && cam_canon && !off && !(opts && opts->full_w)) ? 1u : 0u;
+    }
+    if (opts && opts->containers > RTX_CONTAINERS_BOOK) return fail(RTX_E_INVALID, "containers %u: RTX_CONTAINERS_V1 or RTX_CONTAINERS_BOOK", opts->containers);
+    if (opts && opts->containers == RTX_CONTAINERS_BOOK && s->track_n1) {
+        // every level of the frame runs the plain variants (see book_kernel): one ray format, no LDS tables
+        p.book = 1u;
+        p.canon = 0u;
+        p.tab_mode = (uint32_t)kTabGlobal;
+        p.lds_bytes = 0u;
     }
     for (int l = 0; l < lanes && !fixed; ++l) {
         rc = ensure_work(s, &s->ws[l], cap, p.canon == 0);
