@@ -729,7 +729,21 @@ RTX_HD void traverse_bvh(V& v, T& tally, const Params& p, uint32_t root, V4 o, V
             const float z0 = (a.z - o.z) * iz, z1 = (b.z - o.z) * iz;
             const float tmin = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
             const float tmax = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
-            const float slack = 1e-5f * (fabsf(tmin) + fabsf(tmax)) + 1e-6f;
+            // Slack.  Each of x0 .. z1 is fl(fl(bound - o) * fl(1 / d)): three roundings, so it is within
+            // 3u (1 + O(u)) of the exact slab parameter, relatively (u = 2^-24) — whatever the size of
+            // o: a far origin makes bound - o and the parameter large together.  min / max are exact, so if
+            // the exact slabs overlap (tmin <= tmax) the computed ones satisfy
+            //     tmin - tmax <= 3.1 u (|tmin| + |tmax|),
+            // i.e. a relative slack of 1.6 u on each side already makes the box test conservative for the
+            // arithmetic of this loop.  kSlabRel = 1e-5 = 168 u leaves a factor 100 for the other inexact
+            // party: the f32 triangle test (src/triangle.zig:32-50) accepts points up to a few ulps of
+            // |o| + |p0| outside the exact triangle, more for rays within ~1e-3 rad of its plane, where
+            // 1 / det amplifies the rounding of u and v; the leaf boxes are padded for that in the build
+            // (rtx_bvh.hpp bound_triangle: relative to the box's extent and coordinates), kSlabAbs covers
+            // parameters that round to zero.  Both terms are relative, so the walk culls the same way at
+            // any scale or distance (tests: test_bvh_host.py, test_gpu_parity.py "large group transforms").
+            constexpr float kSlabRel = 1e-5f, kSlabAbs = 1e-6f;
+            const float slack = kSlabRel * (fabsf(tmin) + fabsf(tmax)) + kSlabAbs;
             const bool overlap = (tmin - slack <= tmax + slack) && (tmax + slack >= v.t_lo()) && (tmin - slack <= v.t_hi());
             if (overlap && leaf == rtx_bvh::kNoLeaf) {
                 n = n + 1;  // first child

@@ -137,3 +137,44 @@ def test_triangle_run_is_taken_from_the_tail_whatever_the_type_order():
     assert 0 < whole[1] - n_tris <= 2
     mid.type = 5
     assert run() == whole
+
+
+@pytest.mark.parametrize("label,tf", [
+    ("scale 1000", lambda: su.scaling(1000.0, 1000.0, 1000.0)),
+    ("scale 0.01", lambda: su.scaling(0.01, 0.01, 0.01)),
+    ("far translation", lambda: su.translation(20000.0, -5000.0, 30000.0)),
+    ("rotated, anisotropic, far", lambda: su.compose(su.translation(-3000.0, 100.0, 800.0), su.rotation("z", 0.4), su.rotation("y", 1.1),
+                                                     su.scaling(30.0, 2.0, 9.0))),
+])
+def test_bvh_walk_is_conservative_away_from_the_unit_scale(label, tf):
+    """The slab slack is relative to the slab parameters and the box padding to the coordinates:
+    scaled, far-away and sheared-looking meshes must cull exactly like the unit-scale teapot — nothing the
+    f32 triangle test accepts may be lost.  Rays aim at world-space vertices, edges and interiors from
+    origins near and far (up to 100 mesh diameters away)."""
+    obj = rta.ObjFile(teapot_text(), bound=False)
+    obj.group.transform = tf()
+    world, keep = st.make_world([0, 10, -10, 1], [1, 1, 1], groups=[obj.group])
+    keep.append(obj)
+    flat = rta.FlatScene(world)
+    d = flat.desc
+    m = np.array(obj.group.transform.to_numpy(), dtype=np.float64)
+    rng = np.random.default_rng(5)
+    n = 4000
+    tri = [i for i in range(d.n_shapes) if d.shapes[i].type == 5 and any(d.shapes[i].e0[:3])]
+    pick = rng.choice(tri, size=n)
+    targets = np.zeros((n, 3))
+    for k, i in enumerate(pick):
+        sh = d.shapes[i]
+        p0, e0, e1 = np.array(sh.p0[:3]), np.array(sh.e0[:3]), np.array(sh.e1[:3])
+        u, v = [(0, 0), (0.5, 0), (0.3, 0.3), (1, 0)][k % 4]
+        targets[k] = (m @ np.append(p0 + u * e0 + v * e1, 1.0))[:3]   # object -> world
+    centre, size = targets.mean(axis=0), np.ptp(targets, axis=0).max()
+    dist = size * np.where(np.arange(n) % 3 == 0, 100.0, np.where(np.arange(n) % 3 == 1, 3.0, 0.2))[:, None]
+    dirs = rng.normal(size=(n, 3))
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    origins = targets - dirs * dist
+    dirs[::7, 0] = 0.0
+    o4 = np.concatenate([origins, np.ones((n, 1))], axis=1).astype(np.float32)
+    d4 = np.concatenate([dirs, np.zeros((n, 1))], axis=1).astype(np.float32)
+    n_nodes, n_tris, bad, _ = selftest(world, o4, d4)
+    assert n_tris == 1568 - 512 and bad == 0, label

@@ -798,3 +798,35 @@ def test_book_containers_against_the_shipped_refractive_images(capsys):
         print("\nshipped refractive images, pixels within 1 LSB: " + ", ".join("%s %s %.2f%%" % (k[0], k[1], 100 * v) for k, v in out.items()))
     assert out[("cylinder_world", "book")] > out[("cylinder_world", "v1")]   # the glass cylinder follows the book walk
     assert out[("glass_spheres", "book")] > out[("glass_spheres", "v1")]     # so does the (otherwise stale) glass_spheres image
+
+
+# ---- BVH conservativeness away from the unit scale (the slab slack is relative) ------------
+
+@pytest.mark.parametrize("label,group_tf,frm,to", [
+    ("scale 1000", lambda: su.scaling(1000.0, 1000.0, 1000.0), (0, 3000, -10000, 1), (0, 1000, 0, 1)),
+    ("scale 0.01", lambda: su.scaling(0.01, 0.01, 0.01), (0, 0.03, -0.1, 1), (0, 0.01, 0, 1)),
+    ("far translation", lambda: su.translation(20000.0, -5000.0, 30000.0), (20000, -4997, 29990, 1), (20000, -4999, 30000, 1)),
+    ("rotated, anisotropic, far", lambda: su.compose(su.translation(-3000.0, 100.0, 800.0), su.rotation("z", 0.4), su.rotation("y", 1.1),
+                                                     su.scaling(30.0, 20.0, 9.0)), (-3000, 160, 500, 1), (-3000, 130, 800, 1)),
+])
+def test_bvh_equals_brute_force_under_large_group_transforms(label, group_tf, frm, to):
+    obj = rta.ObjFile(_teapot_text(), bound=False)
+    obj.group.transform = group_tf()
+    light = [frm[0] + 0.3 * abs(frm[2] - to[2]), frm[1] + abs(frm[2] - to[2]), frm[2], 1]
+    world, keep = st.make_world(light, [1, 1, 1], groups=[obj.group])
+    keep.append(obj)
+    cam = rta.camera(160, 120, 1.0, frm, to, (0, 1, 0, 0))
+    scene = rta.Scene(world)
+    a, sa = scene.render(cam)
+    b, sb = scene.render(cam, no_bvh=True)
+    assert sa.kernel_flags & rta.RtxStats.KERNEL_BVH and not sb.kernel_flags & rta.RtxStats.KERNEL_BVH
+    assert a.tobytes() == b.tobytes() and sa.rays_total == sb.rays_total, label
+    assert sa.rays_shadow > 300, "%s: the mesh is not in view (%d hits)" % (label, sa.rays_shadow)
+    scene.close()
+    small = rta.camera(48, 36, 1.0, frm, to, (0, 1, 0, 0))
+    ref, counts = o.render(small, world)
+    scene = rta.Scene(world)
+    gpu, stats = scene.render(small)
+    compare(gpu, ref, "teapot under " + label)
+    assert stats.rays_total == counts.total
+    scene.close()
