@@ -358,6 +358,12 @@ struct Flattener {
         // The world node has no box: a ray never skips it, and its own "subtree" is just itself.
         out.nodes[0].skip = 1;
 
+        // Limit of the static flag: the reference cancels two equal shapes only for rays that intersect
+        // both, i.e. that pass both shapes' group boxes.  Equal shapes sit in the same place, so their
+        // boxes — whatever groups they belong to — are passed or failed together by nearly every ray
+        // and the flag is exact there; a ray that passes one box and not the other (boxes of different
+        // extent around the twins) sees the surviving twin as a predecessor in the reference and not
+        // here.  Keying the flag on the gate chain instead would turn the common case wrong.
         // Shapes equal under std.meta.eql produce equal Intersections that toggle each other out
         // of the n1/n2 container walk (src/intersection.zig:126-137): with m equal shapes only the
         // last one survives, and only when m is odd.

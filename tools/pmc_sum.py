@@ -15,7 +15,8 @@ for path in sys.argv[1:]:
         full = row["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
         k = re.sub(r"<.*", "", full)
         if "k_trace_shade" in full:
-            k += " stats" if re.search(r"true>$", full) else " plain"
+            args = [a.strip() for a in re.search(r"k_trace_shade<([^>]*)>", full).group(1).split(",")]
+            k += " stats" if len(args) > 5 and args[5] == "true" else " plain"  # template flag STATS
         acc[(k, row["Counter_Name"])] += float(row["Counter_Value"])
         n[k].add(row["Dispatch_Id"])
         d = int(row["Dispatch_Id"])

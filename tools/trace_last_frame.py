@@ -18,7 +18,12 @@ def short(n):
 starts = [i for i, r in enumerate(rows) if re.search(r"k_trace_shade<\d+, true", r["Kernel_Name"])]
 if not starts:
     sys.exit("no ray-generating launch found")
-plain = [i for i in starts if re.search(r"false>", rows[i]["Kernel_Name"])] or starts
+def counts_events(name):  # template flag STATS (sixth) of k_trace_shade
+    args = [a.strip() for a in re.search(r"k_trace_shade<([^>]*)>", name).group(1).split(",")]
+    return len(args) > 5 and args[5] == "true"
+
+
+plain = [i for i in starts if not counts_events(rows[i]["Kernel_Name"])] or starts
 first = plain[-1]
 later = [i for i in starts if i > first]
 frame = rows[first:(later[0] if later else len(rows))]
