@@ -57,7 +57,7 @@ class RtxSceneDesc(C.Structure):
                 ("n_materials", u32), ("materials", P(RtxMaterial)),
                 ("n_patterns", u32), ("patterns", P(RtxPattern)),
                 ("n_nodes", u32), ("nodes", P(RtxNode)),
-                ("light_position", f32 * 4), ("light_intensity", f32 * 3), ("reserved", u32)]
+                ("light_position", f32 * 4), ("light_intensity", f32 * 3), ("flags", u32)]
 
 
 class RtxCamera(C.Structure):
@@ -92,6 +92,7 @@ _SIGNATURES = [
     ("rtx_device_count", C.c_int, []),
     ("rtx_scene_create", C.c_int, [P(RtxSceneDesc), C.c_int, P(C.c_void_p)]),
     ("rtx_scene_destroy", None, [C.c_void_p]),
+    ("rtx_scene_refit", C.c_int, [C.c_void_p, P(RtxSceneDesc)]),
     ("rtx_rows_for", C.c_int, [P(RtxCamera), P(RtxOpts), P(u32)]),
     ("rtx_render", C.c_int, [C.c_void_p, P(RtxCamera), P(RtxOpts), P(f32), P(RtxStats)]),
     ("rtx_render_device", C.c_int, [C.c_void_p, P(RtxCamera), P(RtxOpts), C.c_void_p, C.c_void_p, C.c_void_p, P(RtxStats)]),
@@ -316,12 +317,19 @@ class FlatScene:
 class Scene:
     """A scene resident on one GPU (rtx_scene)."""
 
-    def __init__(self, world, device=0):
+    def __init__(self, world, device=0, device_bvh=False):
         flat = FlatScene(world)
+        if device_bvh:
+            flat.desc.flags |= 1  # RTX_SCENE_BVH_DEVICE
         h = C.c_void_p()
         _check(lib().rtx_scene_create(C.byref(flat.desc), device, C.byref(h)))
         self.handle = h
         self.n_shapes = flat.desc.n_shapes
+
+    def refit(self, world):
+        """rtx_scene_refit: the same scene structure with moved shapes."""
+        flat = FlatScene(world)
+        _check(lib().rtx_scene_refit(self.handle, C.byref(flat.desc)))
 
     def close(self):
         if getattr(self, "handle", None) and lib is not None:

@@ -25,18 +25,21 @@
 // Reference citations are file:line into /root/reference.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <string>
 #include <vector>
 
 #include "../../include/rt_scene.h"
 #include "../../include/rtx.h"
 #include "../host/rt_libm.hpp"
 #include "rtx_bvh.hpp"
+#include "rtx_lbvh.hpp"
 
 namespace {
 
@@ -1650,6 +1653,13 @@ struct rtx_scene {
     rtx_bvh::Node* d_bvh_nodes = nullptr;
     rtx_bvh::Tri* d_bvh_tris = nullptr;
     uint32_t n_bvh_nodes = 0, n_bvh_tris = 0;
+    struct DeviceTree {  // a tree built on the device (RTX_SCENE_BVH_DEVICE), kept for rtx_scene_refit
+        rtx_lbvh::Tree* tree;
+        uint32_t node_base, tri_base;
+    };
+    std::vector<DeviceTree> device_trees;
+    std::vector<rtx_node> h_nodes;  // the gates as uploaded (BVH links included): refit re-uploads them with new boxes
+    bool host_trees = false;        // some tree came from the host builder (such a scene cannot be refitted)
     rtx_material* d_materials = nullptr;
     rtx_pattern* d_patterns = nullptr;
     uint32_t n_shapes = 0, n_nodes = 0, n_materials = 0, n_patterns = 0;
@@ -1938,8 +1948,15 @@ struct BvhInfo {
 // Links in rtx_node.reserved: [0] = root + 1 of the tree walked at this node (0: none), [1] = leading
 // shapes of the node tested linearly (all of them if none of its triangles is in a tree).
 // `linear` receives the gates without BVH links (rtx_opts.no_bvh).
+// `on_device` (may be NULL): classes whose tree the caller builds on the device (rtx_lbvh) instead —
+// listed with their hittable triangles, linked later (BvhInfo::root is meaningless until then).
+void prepare_shapes(std::vector<rtx_shape>& shapes);
 void build_bvhs(std::vector<rtx_shape>& shapes, std::vector<rtx_node>& nodes, std::vector<rtx_node>& linear,
-                std::vector<rtx_bvh::Node>& bvh_nodes, std::vector<rtx_bvh::Tri>& bvh_tris, std::vector<BvhInfo>* info = nullptr) {
+                std::vector<rtx_bvh::Node>& bvh_nodes, std::vector<rtx_bvh::Tri>& bvh_tris, std::vector<BvhInfo>* info = nullptr,
+                std::vector<BvhInfo>* on_device = nullptr);
+
+// Identity / diagonal flags and the finished world normals of planes and triangles.
+void prepare_shapes(std::vector<rtx_shape>& shapes) {
     static const float kIdentity[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     for (rtx_shape& sh : shapes) {
         bool ident = true;
@@ -1957,6 +1974,12 @@ void build_bvhs(std::vector<rtx_shape>& shapes, std::vector<rtx_node>& nodes, st
             sh.flags |= kShapeWorldNormal;
         }
     }
+}
+
+void build_bvhs(std::vector<rtx_shape>& shapes, std::vector<rtx_node>& nodes, std::vector<rtx_node>& linear,
+                std::vector<rtx_bvh::Node>& bvh_nodes, std::vector<rtx_bvh::Tri>& bvh_tris, std::vector<BvhInfo>* info,
+                std::vector<BvhInfo>* on_device) {
+    prepare_shapes(shapes);
     for (rtx_node& n : nodes) {
         n.reserved[0] = 0;
         n.reserved[1] = n.n_shapes;
@@ -1985,6 +2008,18 @@ void build_bvhs(std::vector<rtx_shape>& shapes, std::vector<rtx_node>& nodes, st
             for (uint32_t k = lin; k < nodes[i].n_shapes; ++k) tris.push_back(nodes[i].first_shape + k);
         }
         if (tris.size() < rtx_bvh::kMinTris) continue;
+        if (on_device) {
+            std::vector<uint32_t> hittable;  // e0 == 0 can never be hit (see rtx_bvh::build_list)
+            for (uint32_t t : tris) {
+                const rtx_shape& sh = shapes[t];
+                if (!(sh.e0[0] == 0.0f && sh.e0[1] == 0.0f && sh.e0[2] == 0.0f && sh.e0[3] == 0.0f)) hittable.push_back(t);
+            }
+            if (hittable.size() >= rtx_bvh::kMinTris) {
+                for (size_t k = 0; k < members.size(); ++k) nodes[members[k]].reserved[1] = n_lin[k];
+                on_device->push_back(BvhInfo{0u, members.back(), hittable});
+                continue;
+            }
+        }
         const uint32_t root = rtx_bvh::build_list(shapes.data(), tris, bvh_nodes, bvh_tris);
         if (root == rtx_bvh::kNoLeaf) continue;
         for (size_t k = 0; k < members.size(); ++k) nodes[members[k]].reserved[1] = n_lin[k];
@@ -2440,18 +2475,65 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out) {
     std::vector<rtx_node> linear;
     std::vector<rtx_bvh::Node> bvh_nodes;
     std::vector<rtx_bvh::Tri> bvh_tris;
-    build_bvhs(shapes, nodes, linear, bvh_nodes, bvh_tris);
-    s->n_bvh_nodes = (uint32_t)bvh_nodes.size();
-    s->n_bvh_tris = (uint32_t)bvh_tris.size();
+    // Trees come from the host builder (binned SAH) unless the descriptor asks for the device builder
+    // (LBVH, rtx_lbvh.hip): RTX_SCENE_BVH_DEVICE, or RTX_BVH_BUILD=device in the environment (experiments).
+    static const bool env_device = [] {
+        const char* e = getenv("RTX_BVH_BUILD");
+        return e && std::strcmp(e, "device") == 0;
+    }();
+    const bool device_build = (desc->flags & RTX_SCENE_BVH_DEVICE) != 0u || env_device;
+    // RTX_TIMING=1: wall time of the phases of this call on stderr (tools/bvh_build_time.py)
+    static const bool timing = getenv("RTX_TIMING") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "rtx_scene_create: %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
+    std::vector<BvhInfo> deferred;
+    build_bvhs(shapes, nodes, linear, bvh_nodes, bvh_tris, nullptr, device_build ? &deferred : nullptr);
+    s->host_trees = !bvh_nodes.empty();
+    lap(device_build ? "shape records + classes" : "shape records + host trees");
     HIP_TRY_S(upload((void**)&s->d_shapes, shapes.data(), sizeof(rtx_shape) * shapes.size()));
+    lap("shape upload");
     {
         const std::vector<HitRec> hitrecs = build_hitrecs(shapes);
         HIP_TRY_S(upload((void**)&s->d_hitrecs, hitrecs.data(), sizeof(HitRec) * hitrecs.size()));
     }
+    {
+        // Device-built trees: plan each (sizes), then one node array and one triangle array hold the host
+        // trees followed by the device trees, which are emitted in place.
+        size_t total_nodes = bvh_nodes.size(), total_tris = bvh_tris.size();
+        std::string err;
+        for (const BvhInfo& c : deferred) {
+            rtx_lbvh::Tree* tree = nullptr;
+            uint32_t per_layout = 0;
+            const int trc = rtx_lbvh::plan(s->d_shapes, c.shapes.data(), (uint32_t)c.shapes.size(), s->stream, &tree, &per_layout, err);
+            if (trc) return bail(fail(trc == -3 ? RTX_E_HIP : RTX_E_INVALID, "device BVH build: %s", err.c_str()));
+            lap("device tree: plan");
+            s->device_trees.push_back(rtx_scene::DeviceTree{tree, (uint32_t)total_nodes, (uint32_t)total_tris});
+            nodes[c.walk_node].reserved[0] = (uint32_t)total_nodes + 1u;
+            total_nodes += (size_t)per_layout * rtx_bvh::kLayouts;
+            total_tris += c.shapes.size();
+        }
+        if (total_nodes > 0xFFFFFFF0ull) return bail(fail(RTX_E_INVALID, "BVH node array too large"));
+        HIP_TRY_S(hipMalloc(&s->d_bvh_nodes, (total_nodes ? total_nodes : 1) * sizeof(rtx_bvh::Node)));
+        HIP_TRY_S(hipMalloc(&s->d_bvh_tris, (total_tris ? total_tris : 1) * sizeof(rtx_bvh::Tri)));
+        if (!bvh_nodes.empty()) HIP_TRY_S(hipMemcpy(s->d_bvh_nodes, bvh_nodes.data(), sizeof(rtx_bvh::Node) * bvh_nodes.size(), hipMemcpyHostToDevice));
+        if (!bvh_tris.empty()) HIP_TRY_S(hipMemcpy(s->d_bvh_tris, bvh_tris.data(), sizeof(rtx_bvh::Tri) * bvh_tris.size(), hipMemcpyHostToDevice));
+        for (const rtx_scene::DeviceTree& t : s->device_trees) {
+            const int trc = rtx_lbvh::emit(t.tree, s->d_shapes, s->d_bvh_nodes, t.node_base, s->d_bvh_tris, t.tri_base, s->stream, err);
+            if (trc) return bail(fail(trc == -3 ? RTX_E_HIP : RTX_E_INVALID, "device BVH build: %s", err.c_str()));
+            lap("device tree: emit + check");
+        }
+        s->n_bvh_nodes = (uint32_t)total_nodes;
+        s->n_bvh_tris = (uint32_t)total_tris;
+    }
+    lap("tree upload");
+    s->h_nodes = nodes;
     HIP_TRY_S(upload((void**)&s->d_nodes, nodes.data(), sizeof(rtx_node) * nodes.size()));
     HIP_TRY_S(upload((void**)&s->d_nodes_linear, linear.data(), sizeof(rtx_node) * linear.size()));
-    HIP_TRY_S(upload((void**)&s->d_bvh_nodes, bvh_nodes.data(), sizeof(rtx_bvh::Node) * bvh_nodes.size()));
-    HIP_TRY_S(upload((void**)&s->d_bvh_tris, bvh_tris.data(), sizeof(rtx_bvh::Tri) * bvh_tris.size()));
     HIP_TRY_S(upload((void**)&s->d_materials, desc->materials, sizeof(rtx_material) * desc->n_materials));
     HIP_TRY_S(upload((void**)&s->d_patterns, desc->patterns, sizeof(rtx_pattern) * desc->n_patterns));
     HIP_TRY_S(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
@@ -2495,6 +2577,8 @@ void rtx_scene_destroy(rtx_scene* s) {
     if (s->d_hitrecs) (void)hipFree(s->d_hitrecs);
     if (s->d_nodes) (void)hipFree(s->d_nodes);
     if (s->d_nodes_linear) (void)hipFree(s->d_nodes_linear);
+    for (rtx_scene::DeviceTree& t : s->device_trees) rtx_lbvh::destroy(t.tree);
+    s->device_trees.clear();
     if (s->d_bvh_nodes) (void)hipFree(s->d_bvh_nodes);
     if (s->d_bvh_tris) (void)hipFree(s->d_bvh_tris);
     if (s->d_materials) (void)hipFree(s->d_materials);
@@ -2504,6 +2588,65 @@ void rtx_scene_destroy(rtx_scene* s) {
     if (s->ev_end) (void)hipEventDestroy(s->ev_end);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
+}
+
+int rtx_scene_refit(rtx_scene* s, const rtx_scene_desc* desc) {
+    if (!s) return fail(RTX_E_INVALID, "scene is NULL");
+    int rc = validate_desc(desc);
+    if (rc) return rc;
+    if (s->host_trees) return fail(RTX_E_INVALID, "rtx_scene_refit needs a scene whose trees were built on the device (RTX_SCENE_BVH_DEVICE)");
+    if (desc->n_shapes != s->n_shapes || desc->n_nodes != s->n_nodes || desc->n_materials != s->n_materials || desc->n_patterns != s->n_patterns)
+        return fail(RTX_E_INVALID, "rtx_scene_refit: the descriptor has another shape / node / material / pattern count than the scene");
+    for (uint32_t i = 0; i < desc->n_nodes; ++i) {
+        const rtx_node &a = desc->nodes[i], &b = s->h_nodes[i];
+        if (a.first_shape != b.first_shape || a.n_shapes != b.n_shapes || a.skip != b.skip || a.has_bounds != b.has_bounds)
+            return fail(RTX_E_INVALID, "rtx_scene_refit: node %u changed its structure", i);
+    }
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    std::vector<rtx_shape> shapes(desc->shapes, desc->shapes + desc->n_shapes);
+    prepare_shapes(shapes);
+    {   // what a tree holds may move, not change kind: a triangle stays a (hittable) triangle
+        std::vector<rtx_shape> old(s->n_shapes);
+        HIP_TRY(hipMemcpy(old.data(), s->d_shapes, sizeof(rtx_shape) * old.size(), hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < s->n_shapes; ++i) {
+            const bool was_flat = old[i].e0[0] == 0.0f && old[i].e0[1] == 0.0f && old[i].e0[2] == 0.0f && old[i].e0[3] == 0.0f;
+            const bool is_flat = shapes[i].e0[0] == 0.0f && shapes[i].e0[1] == 0.0f && shapes[i].e0[2] == 0.0f && shapes[i].e0[3] == 0.0f;
+            if (old[i].type != shapes[i].type || (shapes[i].type == RTX_TRIANGLE && was_flat != is_flat))
+                return fail(RTX_E_INVALID, "rtx_scene_refit: shape %u changed its type (or became / stopped being degenerate)", i);
+        }
+    }
+    // the scene-wide switches follow the new records
+    s->canon = desc->light_position[3] == 1.0f;
+    for (const rtx_shape& sh : shapes) {
+        const float* m = sh.inverse;
+        if (!(m[12] == 0.0f && m[13] == 0.0f && m[14] == 0.0f && m[15] == 1.0f)) s->canon = false;
+        if (sh.type == RTX_CUBE && !(m[3] == 0.0f && m[7] == 0.0f && m[11] == 0.0f)) s->canon = false;
+    }
+    std::memcpy(s->light_position, desc->light_position, sizeof s->light_position);
+    std::memcpy(s->light_intensity, desc->light_intensity, sizeof s->light_intensity);
+    HIP_TRY(hipMemcpy(s->d_shapes, shapes.data(), sizeof(rtx_shape) * shapes.size(), hipMemcpyHostToDevice));
+    const std::vector<HitRec> hitrecs = build_hitrecs(shapes);
+    HIP_TRY(hipMemcpy(s->d_hitrecs, hitrecs.data(), sizeof(HitRec) * hitrecs.size(), hipMemcpyHostToDevice));
+    for (uint32_t i = 0; i < desc->n_nodes; ++i) {
+        std::memcpy(s->h_nodes[i].bounds_min, desc->nodes[i].bounds_min, sizeof s->h_nodes[i].bounds_min);
+        std::memcpy(s->h_nodes[i].bounds_max, desc->nodes[i].bounds_max, sizeof s->h_nodes[i].bounds_max);
+    }
+    HIP_TRY(hipMemcpy(s->d_nodes, s->h_nodes.data(), sizeof(rtx_node) * s->h_nodes.size(), hipMemcpyHostToDevice));
+    {
+        std::vector<rtx_node> linear = s->h_nodes;
+        for (rtx_node& n : linear) {
+            n.reserved[0] = 0;
+            n.reserved[1] = n.n_shapes;
+        }
+        HIP_TRY(hipMemcpy(s->d_nodes_linear, linear.data(), sizeof(rtx_node) * linear.size(), hipMemcpyHostToDevice));
+    }
+    std::string err;
+    for (const rtx_scene::DeviceTree& t : s->device_trees) {
+        const int trc = rtx_lbvh::refit(t.tree, s->d_shapes, s->d_bvh_nodes, t.node_base, s->d_bvh_tris, t.tri_base, s->stream, err);
+        if (trc) return fail(trc == -3 ? RTX_E_HIP : RTX_E_INVALID, "device BVH refit: %s", err.c_str());
+    }
+    return RTX_OK;
 }
 
 int rtx_profile_collect(rtx_scene* s, rtx_stats* out) {

@@ -830,3 +830,73 @@ def test_bvh_equals_brute_force_under_large_group_transforms(label, group_tf, fr
     compare(gpu, ref, "teapot under " + label)
     assert stats.rays_total == counts.total
     scene.close()
+
+
+# ---- triangle BVH built and refitted on the device (RTX_SCENE_BVH_DEVICE: Morton sort + Karras hierarchy) ----
+
+@pytest.mark.parametrize("level,size", [(1, (160, 120)), (2, (160, 120)), (4, (320, 240))])
+def test_device_built_bvh_gives_the_same_canvas(level, size):
+    world, cam, keep = rta.teapot_scene(_teapot_text(level), *size)
+    host = rta.Scene(world)
+    want, sw = host.render(cam)
+    host.close()
+    dev = rta.Scene(world, device_bvh=True)
+    got, sg = dev.render(cam)
+    lin, sl = dev.render(cam, no_bvh=True)
+    assert sg.kernel_flags & rta.RtxStats.KERNEL_BVH and sg.bvh_box_tests > 0 and not sl.kernel_flags & rta.RtxStats.KERNEL_BVH
+    assert got.tobytes() == want.tobytes() == lin.tobytes()
+    assert sg.rays_total == sw.rays_total == sl.rays_total and sg.rays_shadow > 1000
+    dev.close()
+
+
+def test_device_built_bvh_on_the_composite_matches_the_oracle():
+    world, cam, keep = rta.composite_scene(_teapot_text(), 96, 72)
+    ref, counts = o.render(cam, world)
+    scene = rta.Scene(world, device_bvh=True)
+    gpu, stats = scene.render(cam)
+    compare(gpu, ref, "composite, device-built BVH")
+    assert stats.rays_total == counts.total
+    book, _ = scene.render(cam, book=True)  # the predecessor walk over a device tree
+    o.lib().oracle_set_containers(1)
+    try:
+        ref_book, _ = o.render(cam, world)
+    finally:
+        o.lib().oracle_set_containers(0)
+    compare(book, ref_book, "composite, device-built BVH (book)")
+    scene.close()
+
+
+def test_refit_follows_a_moving_mesh():
+    def world_at(angle, lift):
+        obj = rta.ObjFile(_teapot_text(), bound=False)
+        obj.group.transform = su.compose(su.translation(0.0, lift, 0.0), su.rotation("y", angle))
+        w, keep = st.make_world([-6, 9, -8, 1], [1, 1, 1], groups=[obj.group])
+        keep.append(obj)
+        return w, keep
+
+    cam = rta.camera(200, 150, 1.0, (0, 4, -11, 1), (0, 1.5, 0, 1), (0, 1, 0, 0))
+    w0, k0 = world_at(0.0, 0.0)
+    scene = rta.Scene(w0, device_bvh=True)
+    first, _ = scene.render(cam)
+    for angle, lift in ((0.4, 0.0), (1.3, 0.8), (3.0, -0.5)):
+        w1, k1 = world_at(angle, lift)
+        scene.refit(w1)
+        moved, sm = scene.render(cam)
+        fresh_scene = rta.Scene(w1)  # host-built tree over the moved mesh
+        fresh, sf = fresh_scene.render(cam)
+        fresh_scene.close()
+        assert moved.tobytes() == fresh.tobytes() and sm.rays_total == sf.rays_total
+        assert moved.tobytes() != first.tobytes()
+        assert moved.tobytes() == scene.render(cam, no_bvh=True)[0].tobytes()
+    scene.refit(w0)
+    assert scene.render(cam)[0].tobytes() == first.tobytes()
+    scene.close()
+    host_built = rta.Scene(w0)
+    with pytest.raises(rta.RtxError, match="built on the device"):
+        host_built.refit(w0)
+    host_built.close()
+    other, _cam, ko = rta.teapot_scene(_teapot_text(2), 64, 64)
+    dev = rta.Scene(w0, device_bvh=True)
+    with pytest.raises(rta.RtxError):
+        dev.refit(other)  # another structure
+    dev.close()
