@@ -303,6 +303,34 @@ def main():
         want8 = rgb8[(d2h_steps - 1) & 1].cpu()
         assert torch.equal(host8[(d2h_steps - 1) & 1], want8), "the host copy differs from the device canvas"
 
+        # --- the f64 reporting instantiation on the same frame (north_star's FP64 question; parity mode stays f32) ---
+        try:
+            f64_frames = 5
+            scene.render_device(fcam, rgb.data_ptr(), rgb8[0].data_ptr(), stream=stream, lanes=1, f64=True)  # allocates the double queues
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            for _ in range(f64_frames):
+                scene.render_device(fcam, rgb.data_ptr(), rgb8[0].data_ptr(), stream=stream, lanes=1, f64=True)
+            torch.cuda.synchronize()
+            ms64 = (time.perf_counter() - t2) / f64_frames * 1e3
+            img64 = rgb8[0].cpu().numpy()
+            scene.render_device(fcam, rgb.data_ptr(), rgb8[0].data_ptr(), stream=stream, lanes=1)
+            torch.cuda.synchronize()
+            img32 = rgb8[0].cpu().numpy()
+            diff = np.abs(img64.astype(np.int32) - img32.astype(np.int32)).max(axis=-1)
+            extra["f64_report"] = {
+                "frame_ms": ms64, "mrays_per_s": rays_step / ms64 / 1e3,
+                "achieved_tflops_whole_frame": trace_shade_flops(stats) / (ms64 * 1e-3) / 1e12,
+                "fp64_vector_peak_tflops": 78.6,
+                "frac_of_fp64_vector_peak": trace_shade_flops(stats) / (ms64 * 1e-3) / 1e12 / 78.6,
+                "pixels_within_1_lsb_of_f32": float((diff <= 1).mean()), "pixels_identical_to_f32": float((diff == 0).mean()),
+                "note": "rtx_opts.real = RTX_REAL_F64: every computed quantity, the ray queues and the ray-tree nodes in double, scene "
+                        "records f32; plainest kernel variants (tables in global memory, four-lane arithmetic), 2 waves per SIMD; flops are "
+                        "the f32 frame's event counts priced with the same table, over the whole frame time (not one kernel)",
+            }
+        except rta.RtxError as e:  # e.g. not enough memory for the double queues next to the f32 ones
+            extra["f64_report"] = {"error": str(e)}
+
         # --- BASELINE.json's other single-GPU configurations, a few frames each ---
         if not args.no_configs:
             extra["configs"] = other_configs(rta, torch, dev, stream, obj_text)

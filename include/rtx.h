@@ -160,7 +160,16 @@ typedef struct rtx_opts {
                               0 = auto (2 for multi-level frames of >= 4 Mpx, where it cuts the frame time
                               by 13-17 %; 1 otherwise: the fork/join costs more than it wins on short frames) */
     uint32_t containers;   /* RTX_CONTAINERS_*: how prepareComputationsForRefraction's container walk compares entries */
+    uint32_t real;         /* RTX_REAL_*: the arithmetic type of the frame */
+    uint32_t reserved;
 } rtx_opts;
+
+/* rtx_opts.real.  F32 (default) is the reference's own arithmetic (src/tuple.zig:6: Tuple = @Vector(4, f32)) and
+ * the parity mode.  F64 runs the same kernels instantiated over double — every computed quantity, the ray
+ * queues and the ray-tree nodes; the scene records stay f32 — a reporting instantiation for the FP64 vector
+ * roofline BASELINE.json's north_star asks about; its canvas differs from the reference's f32 arithmetic
+ * where rounding decides (tests compare it with the oracle's own f64 build).  Plainest kernel variants only. */
+enum { RTX_REAL_F32 = 0, RTX_REAL_F64 = 1 };
 
 /* rtx_opts.containers.  V1 (default) is the reference as written: std.meta.eql on whole Intersections,
  * t included (src/intersection.zig:104,128), so an exit never removes its entry and n1 is the index of
@@ -201,7 +210,8 @@ enum {
     RTX_KERNEL_BVH         = 1u << 1, /* some gate's triangle run is walked through its BVH */
     RTX_KERNEL_LDS_TABLES  = 1u << 2, /* every per-lane scene table staged in LDS */
     RTX_KERNEL_TRACK_N1    = 1u << 3, /* n1 predecessor tracked (some material is transparent) */
-    RTX_KERNEL_LDS_HIT_RECORDS = 1u << 4 /* 16-byte hit records, materials and patterns staged in LDS; shape records in global memory */
+    RTX_KERNEL_LDS_HIT_RECORDS = 1u << 4, /* 16-byte hit records, materials and patterns staged in LDS; shape records in global memory */
+    RTX_KERNEL_F64         = 1u << 5  /* the double-precision instantiation (rtx_opts.real = RTX_REAL_F64) */
 };
 
 typedef struct rtx_scene rtx_scene; /* opaque; owns the device copies */

@@ -270,6 +270,7 @@ int rtx_multi_create(const rtx_scene_desc* desc, const int* devices, uint32_t n_
 void rtx_multi_destroy(rtx_multi* m) {
     if (!m) return;
     for (Gpu& g : m->gpus) {
+        if (!g.scene && !g.stream && !g.d_rgb && !g.d_rgb8) continue;  // never set up (rtx_multi_create failed before it)
         (void)hipSetDevice(g.device);
         if (g.stream) {
             (void)hipStreamSynchronize(g.stream);
