@@ -110,6 +110,7 @@ _SIGNATURES = [
     ("rtx_bvh_selftest", C.c_int, [P(RtxSceneDesc), P(f32), P(f32), u32, P(u32), P(u32), P(u32)]),
     ("rtx_bvh_selftest_work", None, [P(C.c_uint64), P(C.c_uint64)]),
     ("rtx_last_error", C.c_char_p, []),
+    ("rtx_struct_size", u32, [u32]),
     ("rt_camera_init", None, [u32, u32, f32, P(f32), P(f32), P(f32), P(st.Camera)]),
     ("rt_ray_for_pixel", None, [P(st.Camera), u32, u32, P(st.Ray)]),
     ("rt_render", C.c_int, [P(st.Camera), P(st.World), P(f32), P(st.RayCounts)]),

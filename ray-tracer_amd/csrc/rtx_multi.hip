@@ -295,6 +295,20 @@ int rtx_multi_render_device(rtx_multi* m, const rtx_camera* cam, const rtx_opts*
     return multi_render(m, cam, opts, chunks_per_gpu, (float*)d_rgb_out, (uint8_t*)d_rgb8_out, true, stats);
 }
 
+uint32_t rtx_struct_size(uint32_t which) {
+    switch (which) {
+    case 0: return (uint32_t)sizeof(rtx_shape);
+    case 1: return (uint32_t)sizeof(rtx_material);
+    case 2: return (uint32_t)sizeof(rtx_pattern);
+    case 3: return (uint32_t)sizeof(rtx_node);
+    case 4: return (uint32_t)sizeof(rtx_scene_desc);
+    case 5: return (uint32_t)sizeof(rtx_camera);
+    case 6: return (uint32_t)sizeof(rtx_opts);
+    case 7: return (uint32_t)sizeof(rtx_stats);
+    default: return 0u;
+    }
+}
+
 int rtx_strip_row_map(const rtx_camera* cam, const rtx_opts* opts, uint32_t* rows_out, uint32_t cap, uint32_t* n_rows) {
     uint32_t rows = 0;
     int rc = rtx_rows_for(cam, opts, &rows);
