@@ -153,6 +153,9 @@ def main():
     ap.add_argument("--lanes", type=int, default=1, help="rtx_opts.lanes for the timed frames (0 = the library's choice)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline legs")
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configs")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="only the timed frame loop: no D2H leg, no f64 report, no other configs, no CPU legs (what profiles/ traces: "
+                         "every k_trace_shade launch of the run is then one of the headline frame, running alone)")
     ap.add_argument("--no-events", action="store_true", help="experiment: no per-launch HIP events in the timed loop")
     ap.add_argument("--whole-frames", action="store_true",
                     help="N > 1: deal whole frames to the ranks (weak scaling) instead of splitting every frame into strips")
@@ -273,7 +276,9 @@ def main():
         rays_step = float(rays_local)
 
     extra = {}
-    if n == 1 and rank == 0:
+    if args.headline_only:
+        args.no_cpu = args.no_configs = True
+    if n == 1 and rank == 0 and not args.headline_only:
         # --- the same frame loop with the u8 canvas landing in pinned host memory (SURVEY §8d's frame time) ---
         copy_stream = torch.cuda.Stream(device=dev)
         host8 = [torch.empty(rgb8[0].shape, dtype=torch.uint8, pin_memory=True) for _ in range(2)]

@@ -22,7 +22,10 @@
 namespace rtx_bvh {
 
 constexpr uint32_t kNoLeaf = 0xFFFFFFFFu;
-constexpr uint32_t kLeafTris = 4;
+#ifndef RTX_LEAF_TRIS
+#define RTX_LEAF_TRIS 4
+#endif
+constexpr uint32_t kLeafTris = RTX_LEAF_TRIS;  // at most 7 (three bits in the leaf link)
 constexpr uint32_t kMinTris = 16;  // shorter triangle runs stay on the linear path
 
 struct Node {  // 32 bytes

@@ -12,7 +12,7 @@ for path in sys.argv[1:]:
     per_dispatch = defaultdict(dict)
     names = {}
     for row in csv.DictReader(open(path)):
-        full = row["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
+        full = row["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").replace("f32::", "").split("(")[0]  # f64:: stays
         k = re.sub(r"<.*", "", full)
         if "k_trace_shade" in full:
             args = [a.strip() for a in re.search(r"k_trace_shade<([^>]*)>", full).group(1).split(",")]

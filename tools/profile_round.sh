@@ -7,9 +7,10 @@ out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 # 1. the bench command under --kernel-trace --stats (per-kernel averages must agree with bench.py's HIP events).
-#    --no-configs --no-cpu: the other configurations launch the same kernel instantiations on other frames and
-#    would pool into the same rows; with them off every k_trace_shade launch in the trace is one of the headline frame.
-timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $out/bench -o bench --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --no-configs --no-cpu > $out/bench.log 2>&1
+#    --headline-only: the other legs (D2H loop, f64 report, other configurations) launch the same kernel instantiations
+#    on other frames or next to copy kernels and would pool into the same rows; with them off every k_trace_shade
+#    launch in the trace is one of the headline frame, running alone.
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $out/bench -o bench --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --headline-only > $out/bench.log 2>&1
 grep "^{\"metric\"" $out/bench.log > $out/bench.json
 #    and the whole default command, unprofiled (what the driver runs)
 timeout -k 10 400 python3 $GRAFT_REPO_ROOT/bench.py > $out/bench_full.log 2>&1

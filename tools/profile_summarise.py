@@ -27,7 +27,7 @@ def pmc(path):
     acc = defaultdict(float)
     n = defaultdict(set)
     for row in csv.DictReader(open(path)):
-        full = row["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
+        full = row["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").replace("f32::", "").split("(")[0]  # f64:: stays
         k = re.sub(r"<.*", "", full)
         if "k_trace_shade" in full:
             args = [a.strip() for a in re.search(r"k_trace_shade<([^>]*)>", full).group(1).split(",")]
@@ -38,7 +38,7 @@ def pmc(path):
 
 
 shutil.copy(os.path.join(src, "bench", "bench_kernel_stats.csv"), os.path.join(dst, tag + "_bench_kernel_stats.csv"))
-shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, tag + "_bench.json"))            # the profiled command: --no-configs --no-cpu
+shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, tag + "_bench.json"))            # the profiled command: --headline-only
 shutil.copy(os.path.join(src, "bench_full.json"), os.path.join(dst, tag + "_bench_full.json"))  # the default command, unprofiled
 for name in ("teapot", "composite4k", "composite8k", "glass_spheres", "fresnel", "cylinder_world"):
     shutil.copy(os.path.join(src, name, "k_kernel_stats.csv"), os.path.join(dst, "%s_%s_kernel_stats.csv" % (tag, name)))

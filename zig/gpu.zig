@@ -2,8 +2,8 @@
 //! libraytracer_amd.so: a drop-in for `camera.render` (src/camera.zig:84-105) and `world.colorAt`
 //! (src/world.zig:81-83) that runs the per-pixel loop on MI355X GPUs.
 //!
-//! Place this file in the reference's `src/`, add `pub usingnamespace @import("gpu.zig");` nothing —
-//! call `gpu.render(allocator, camera, world)` where the samples call `rt.render(...)`, and link with
+//! Place this file in the reference's `src/`, export it from src/main.zig (`pub const gpu = @import("gpu.zig");`),
+//! call `rt.gpu.render(allocator, camera, world)` where the samples call `rt.render(...)`, and link with
 //!     exe.linkSystemLibrary("raytracer_amd"); exe.linkLibC(); exe.addLibPath("<repo>/ray-tracer_amd");
 //!
 //! NOT COMPILED in this repository's image (it has no Zig toolchain, SURVEY.md fact 3): the extern
