@@ -150,7 +150,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--lanes", type=int, default=1, help="rtx_opts.lanes for the timed frames (0 = the library's choice)")
+    ap.add_argument("--lanes", type=int, default=1, help="rtx_opts.lanes for the timed frames (2 is an experiment: see rtx.h)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline legs")
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configs")
     ap.add_argument("--headline-only", action="store_true",

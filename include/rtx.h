@@ -157,8 +157,10 @@ typedef struct rtx_opts {
                               0 / 1 (A/B check of the canonical-w kernels; same canvas, slower) */
     uint32_t lanes;        /* batches of a frame alternate between this many work-buffer sets on as many
                               streams, so one batch's kernels fill the tails of the other's: 1 or 2;
-                              0 = auto (2 for multi-level frames of >= 4 Mpx, where it cuts the frame time
-                              by 13-17 %; 1 otherwise: the fork/join costs more than it wins on short frames) */
+                              0 = 1.  Two lanes are opt-in: they win 1-8 % on 4K-8K mesh frames when the runtime
+                              puts the two lane streams on different hardware queues and lose 24 % when it puts
+                              them on one (which depends on the streams the process created before): measure
+                              both in the calling process */
     uint32_t containers;   /* RTX_CONTAINERS_*: how prepareComputationsForRefraction's container walk compares entries */
     uint32_t real;         /* RTX_REAL_*: the arithmetic type of the frame */
     uint32_t reserved;

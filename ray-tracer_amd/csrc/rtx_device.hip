@@ -975,16 +975,23 @@ int render_impl_t(rtx_scene* s, const rtx_camera* cam, const rtx_opts* opts, flo
     // Two lanes: a frame that would be one batch is cut in two halves that run on two streams
     // with their own work buffers, so each half's kernels fill the other's tails and empty
     // levels.  Frames with per-launch events (profile) stay on one lane: their kernels must run
-    // alone to be timed.  rtx_opts.lanes picks; 0 = auto: only multi-level frames of >= 4 Mpx,
-    // because the fork/join between streams costs tens of microseconds per frame (a 1080p frame
-    // loop loses 14 % to it, a 4K mesh frame gains 13 %).  RTX_LANES overrides auto (A/B).
+    // alone to be timed.  rtx_opts.lanes picks; 0 = one lane.  Two lanes are opt-in because what
+    // they gain is small and what they can lose is not: the runtime multiplexes streams onto a few
+    // hardware queues (GPU_MAX_HW_QUEUES, 4 here), and which queue a stream gets depends on what
+    // else the process created before.  On two queues the halves overlap (4K composite frame 1.69
+    // instead of 1.71 ms, 8K 5.65 instead of 6.10 ms); on one queue they run one after the other,
+    // each with the longer tails of a half-size batch (2.13 ms - the same library, the same frame,
+    // in bench.py's process; kernel traces of both in DESIGN.md section 5c).  A caller that wants
+    // them measures both in its own process.  Lane streams at different priorities (separate
+    // queue pools) were tried as a way to force two queues and hung that same process: not kept.
+    // RTX_LANES sets the default for opts.lanes == 0 (A/B).
     static const int lanes_env = [] {
         const char* e = getenv("RTX_LANES");
         return e ? atoi(e) : 0;
     }();
     int lanes = (int)((opts && opts->lanes) ? opts->lanes : (lanes_env > 0 ? (uint32_t)lanes_env : 0u));
     if (lanes > kLanes) return fail(RTX_E_INVALID, "lanes %d exceeds %d", lanes, kLanes);
-    if (lanes == 0) lanes = (s->can_spawn && (uint64_t)plan.rows_local * W >= (1u << 22)) ? kLanes : 1;
+    if (lanes == 0) lanes = 1;
     if (profile || plan.rows_local < 64u || fixed) lanes = 1;
     if (lanes > 1) {
         const uint32_t half = ((plan.rows_local + (uint32_t)lanes - 1u) / (uint32_t)lanes + 7u) & ~7u;
