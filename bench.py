@@ -385,7 +385,8 @@ def main():
                 "share_of_step": (prof.ms_trace_shade / profiled_steps) / (dt / args.steps * 1e3) if dt > 0 and profiled_steps else None,
                 "events": {"shape_tests": list(stats.shape_tests), "gate_tests": stats.gate_tests, "bvh_box_tests": stats.bvh_box_tests,
                            "bvh_triangle_tests": stats.bvh_triangle_tests, "hits": stats.rays_shadow,
-                           "hits_patterned": stats.hits_patterned, "hits_transparent": stats.hits_transparent},
+                           "hits_patterned": stats.hits_patterned, "hits_transparent": stats.hits_transparent,
+                           "shadow_rays_skipped": stats.shadow_rays_skipped},
                 "note": "f32 VALU roofline (no MFMA: divergent per-lane scalar math); peak = 78.6 TFLOP/s, the f32 vector peak for "
                         "unpacked per-lane code (SURVEY 8d); frac_of_unfused_issue_rate prices the same figure against 39.3 "
                         "(parity forbids FMA contraction: one flop per VALU instruction), frac_of_spec_peak against 157.3 (packed "

@@ -163,7 +163,9 @@ typedef struct rtx_opts {
                               both in the calling process */
     uint32_t containers;   /* RTX_CONTAINERS_*: how prepareComputationsForRefraction's container walk compares entries */
     uint32_t real;         /* RTX_REAL_*: the arithmetic type of the frame */
-    uint32_t reserved;
+    uint32_t all_shadows;  /* 1: traverse every isShadowed call, also where the light is behind the surface and the
+                              answer cannot reach the colour (A/B check; same canvas, same counts but
+                              rtx_stats.shadow_rays_skipped == 0, slower) */
 } rtx_opts;
 
 /* rtx_opts.real.  F32 (default) is the reference's own arithmetic (src/tuple.zig:6: Tuple = @Vector(4, f32)) and
@@ -204,6 +206,9 @@ typedef struct rtx_stats {
     uint64_t bvh_triangle_tests; /* Triangle.intersect calls on BVH leaves (src/triangle.zig:32-50) */
     uint64_t gate_tests;         /* bnd.intersect calls on group boxes (src/group.zig:58, src/bounds.zig:149-158) */
     uint64_t shape_tests[6];     /* Shape.intersect calls on linearly tested shapes, by RTX_* type */
+    uint64_t shadow_rays_skipped; /* isShadowed calls counted in rays_shadow but not traversed: the light is behind the
+                                    surface (src/material.zig:72-79), where lighting() returns the ambient term shadowed
+                                    or not.  0 for a scene with a negative, -0 or non-finite colour / ambient / intensity */
 } rtx_stats;
 
 /* rtx_stats.kernel_flags: template flags of the trace+shade kernel a frame dispatched. */
@@ -226,7 +231,8 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out);
 void rtx_scene_destroy(rtx_scene* scene);
 
 /*
- * The same scene after its shapes moved (new vertices, transforms, boxes, materials' values, light):
+ * The same scene after its shapes moved (new vertices, transforms, boxes, light; materials and patterns stay
+ * as created: they decide the work buffers' layout):
  * `desc` must have the structure the scene was created with (same counts, same node ranges, every shape
  * of the same type).  Records are uploaded again and the device-built trees are refitted — boxes
  * recomputed bottom-up over the unchanged topology — instead of rebuilt.  Needs RTX_SCENE_BVH_DEVICE at

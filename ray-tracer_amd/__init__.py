@@ -68,7 +68,7 @@ class RtxCamera(C.Structure):
 class RtxOpts(C.Structure):
     _fields_ = [("depth", u32), ("rows_quirk", u32), ("batch_pixels", u32), ("strip_rows", u32),
                 ("strip_count", u32), ("strip_index", u32), ("compact_rows", u32), ("profile", u32),
-                ("no_bvh", u32), ("full_w", u32), ("lanes", u32), ("containers", u32), ("real", u32), ("reserved", u32)]
+                ("no_bvh", u32), ("full_w", u32), ("lanes", u32), ("containers", u32), ("real", u32), ("all_shadows", u32)]
 
 
 class RtxStats(C.Structure):
@@ -78,7 +78,7 @@ class RtxStats(C.Structure):
                 ("ms_total", f32), ("ms_trace_shade", f32), ("ms_combine", f32),
                 ("launches_trace_shade", u32), ("launches_combine", u32), ("rows_rendered", u32), ("kernel_flags", u32),
                 ("bvh_box_tests", C.c_uint64), ("bvh_triangle_tests", C.c_uint64), ("gate_tests", C.c_uint64),
-                ("shape_tests", C.c_uint64 * 6)]
+                ("shape_tests", C.c_uint64 * 6), ("shadow_rays_skipped", C.c_uint64)]
 
     KERNEL_CANONICAL_W, KERNEL_BVH, KERNEL_LDS_TABLES, KERNEL_TRACK_N1, KERNEL_LDS_HIT_RECORDS = 1, 2, 4, 8, 16  # rtx.h RTX_KERNEL_*
     KERNEL_F64 = 32
@@ -341,13 +341,14 @@ class Scene:
     __del__ = close
 
     def render(self, cam, rows_quirk=True, depth=0, batch_pixels=0, strips=None, compact_rows=False, profile=False,
-               no_bvh=False, full_w=False, lanes=0, book=False, f64=False):
+               no_bvh=False, full_w=False, lanes=0, book=False, f64=False, all_shadows=False):
         """render() — src/camera.zig:84-105 -> (canvas float32 [rows, W, 3], RtxStats)."""
         L = lib()
         rc = flatten_camera(cam) if isinstance(cam, st.Camera) else cam
         opts = RtxOpts(depth=depth, rows_quirk=1 if rows_quirk else 0, batch_pixels=batch_pixels,
                        compact_rows=1 if compact_rows else 0, profile=1 if profile else 0, no_bvh=1 if no_bvh else 0,
-                       full_w=1 if full_w else 0, lanes=lanes, containers=1 if book else 0, real=1 if f64 else 0)
+                       full_w=1 if full_w else 0, lanes=lanes, containers=1 if book else 0, real=1 if f64 else 0,
+                       all_shadows=1 if all_shadows else 0)
         if strips is not None:
             opts.strip_rows, opts.strip_count, opts.strip_index = strips
         rows = u32()
@@ -365,7 +366,8 @@ class Scene:
         opts = RtxOpts(depth=kw.get("depth", 0), rows_quirk=1 if kw.get("rows_quirk", True) else 0,
                        batch_pixels=kw.get("batch_pixels", 0), compact_rows=1 if kw.get("compact_rows", False) else 0,
                        profile=1 if kw.get("profile", False) else 0, no_bvh=1 if kw.get("no_bvh", False) else 0,
-                       full_w=1 if kw.get("full_w", False) else 0, lanes=kw.get("lanes", 0), real=1 if kw.get("f64", False) else 0)
+                       full_w=1 if kw.get("full_w", False) else 0, lanes=kw.get("lanes", 0), real=1 if kw.get("f64", False) else 0,
+                       all_shadows=1 if kw.get("all_shadows", False) else 0)
         if kw.get("strips") is not None:
             opts.strip_rows, opts.strip_count, opts.strip_index = kw["strips"]
         stats = RtxStats() if want_stats else None

@@ -25,6 +25,9 @@ constexpr uint32_t kNoLeaf = 0xFFFFFFFFu;
 #ifndef RTX_LEAF_TRIS
 #define RTX_LEAF_TRIS 4
 #endif
+#ifndef RTX_SAH_AXES
+#define RTX_SAH_AXES 3
+#endif
 constexpr uint32_t kLeafTris = RTX_LEAF_TRIS;  // at most 7 (three bits in the leaf link)
 constexpr uint32_t kMinTris = 16;  // shorter triangle runs stay on the linear path
 
@@ -204,43 +207,55 @@ struct Builder {
             if (n <= 7) return make_leaf(box, lo, hi);
             mid = lo + n / 2;
         } else {
-            // Binned SAH on the widest centroid axis.
+            // Binned SAH: the cheapest of the 15 splits of each axis (RTX_SAH_AXES = 1: widest centroid axis only).
             constexpr int kBins = 16;
-            Box bbox[kBins];
-            size_t bcount[kBins] = {0};
-            for (auto& b : bbox) b.reset();
-            const double scale = kBins / ext;
-            auto bin_of = [&](const Prim& p) {
-                int b = (int)((p.centroid[axis] - cbox.mn[axis]) * scale);
-                return b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
-            };
-            for (size_t i = lo; i < hi; ++i) {
-                const int b = bin_of(prims[i]);
-                bbox[b].add(prims[i].box);
-                bcount[b]++;
-            }
             double best = INFINITY;
-            int best_split = -1;
-            for (int sidx = 1; sidx < kBins; ++sidx) {
-                Box l, r;
+            int best_split = -1, best_axis = axis;
+            for (int pass = 0; pass < RTX_SAH_AXES; ++pass) {
+                const int ax = RTX_SAH_AXES == 1 ? axis : pass;
+                const double e = cbox.mx[ax] - cbox.mn[ax];
+                if (!(e > 0)) continue;
+                Box bbox[kBins];
+                size_t bcount[kBins] = {0};
+                for (auto& b : bbox) b.reset();
+                const double scale = kBins / e;
+                for (size_t i = lo; i < hi; ++i) {
+                    int b = (int)((prims[i].centroid[ax] - cbox.mn[ax]) * scale);
+                    b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+                    bbox[b].add(prims[i].box);
+                    bcount[b]++;
+                }
+                Box racc[kBins];  // racc[s] = union of bins s .. kBins-1
+                size_t rcount[kBins];
+                {
+                    Box r;
+                    r.reset();
+                    size_t nr = 0;
+                    for (int b = kBins - 1; b >= 0; --b) {
+                        if (bcount[b]) {
+                            r.add(bbox[b]);
+                            nr += bcount[b];
+                        }
+                        racc[b] = r;
+                        rcount[b] = nr;
+                    }
+                }
+                Box l;
                 l.reset();
-                r.reset();
-                size_t nl = 0, nr = 0;
-                for (int b = 0; b < sidx; ++b)
-                    if (bcount[b]) {
-                        l.add(bbox[b]);
-                        nl += bcount[b];
+                size_t nl = 0;
+                for (int sidx = 1; sidx < kBins; ++sidx) {
+                    if (bcount[sidx - 1]) {
+                        l.add(bbox[sidx - 1]);
+                        nl += bcount[sidx - 1];
                     }
-                for (int b = sidx; b < kBins; ++b)
-                    if (bcount[b]) {
-                        r.add(bbox[b]);
-                        nr += bcount[b];
+                    const size_t nr = rcount[sidx];
+                    if (!nl || !nr) continue;
+                    const double cost = l.area() * (double)nl + racc[sidx].area() * (double)nr;
+                    if (cost < best) {
+                        best = cost;
+                        best_split = sidx;
+                        best_axis = ax;
                     }
-                if (!nl || !nr) continue;
-                const double cost = l.area() * (double)nl + r.area() * (double)nr;
-                if (cost < best) {
-                    best = cost;
-                    best_split = sidx;
                 }
             }
             if (best_split < 0) {
@@ -248,6 +263,12 @@ struct Builder {
                 std::nth_element(prims.begin() + lo, prims.begin() + mid, prims.begin() + hi,
                                  [&](const Prim& a, const Prim& b) { return a.centroid[axis] < b.centroid[axis]; });
             } else {
+                axis = best_axis;
+                const double scale = kBins / (cbox.mx[axis] - cbox.mn[axis]);
+                auto bin_of = [&](const Prim& p) {
+                    int b = (int)((p.centroid[axis] - cbox.mn[axis]) * scale);
+                    return b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+                };
                 // stable_partition keeps the build deterministic
                 auto it = std::stable_partition(prims.begin() + lo, prims.begin() + hi,
                                                 [&](const Prim& p) { return bin_of(p) < best_split; });

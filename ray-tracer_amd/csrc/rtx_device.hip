@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -108,7 +109,8 @@ struct ShardCounters {  // one 128-byte line per shard
     unsigned long long hit_kinds;  // low 32: hits on patterned materials, high 32: on transparent ones
     uint32_t hits[kLevels];        // hits at level d == isShadowed calls
     uint32_t refr[kLevels];        // per level d: refracted rays queued for level d + 1 (their own region)
-    uint32_t pad[32 - 2 * kLevels - 2 - kLevels - kLevels];
+    uint32_t dark;                 // hits with the light behind the surface whose isShadowed call was not traversed
+    uint32_t pad[32 - 2 * kLevels - 2 - kLevels - kLevels - 1];
 };
 static_assert(sizeof(ShardCounters) == 128, "one cache line per shard");
 
@@ -158,6 +160,7 @@ struct Totals {
     unsigned long long hits_patterned;
     unsigned long long hits_transparent;
     unsigned long long bvh_box, bvh_tri, gate, shape[6];
+    unsigned long long shadow_skipped;
 };
 
 // Event tally of one wave of a STATS kernel; the other kernels carry the empty form and pay nothing.
@@ -165,10 +168,23 @@ struct Totals {
 template <bool ON>
 struct Tally {
     uint32_t bvh_box = 0, bvh_tri = 0, gate = 0, shape[6] = {0, 0, 0, 0, 0, 0};
+#if defined(RTX_EXP_SLOTS) && defined(__HIP_DEVICE_COMPILE__)
+    // Experiment (tools/build_variant.sh slots -DRTX_EXP_SLOTS): count the lane SLOTS each loop iteration
+    // occupies (64 per wave iteration) instead of the lanes that test; events / slots = lane utilisation.
+    __device__ __forceinline__ void slot(uint32_t& c) {
+        const unsigned long long m = __ballot(1);
+        if (__lane_id() == (uint32_t)(__ffsll((long long)m) - 1)) c += 64u;
+    }
+    __device__ __forceinline__ void box() { slot(bvh_box); }
+    __device__ __forceinline__ void tri() { slot(bvh_tri); }
+    __device__ __forceinline__ void gates(bool lane_tests) { gate += __ballot(lane_tests) ? 64u : 0u; }
+    __device__ __forceinline__ void shapes(uint32_t type, bool lane_tests) { shape[type] += __ballot(lane_tests) ? 64u : 0u; }
+#else
     RTX_HD void box() { ++bvh_box; }
     RTX_HD void tri() { ++bvh_tri; }
     __device__ __forceinline__ void gates(bool lane_tests) { gate += __popcll(__ballot(lane_tests)); }
     __device__ __forceinline__ void shapes(uint32_t type, bool lane_tests) { shape[type] += __popcll(__ballot(lane_tests)); }
+#endif
 };
 template <>
 struct Tally<false> {
@@ -218,7 +234,7 @@ using namespace f32;  // the host side below speaks f32 unless it says f64::
 // one wave, lane k owns shard k.  `reset` starts a new frame's totals.
 __global__ void k_accumulate(Counters* c, Totals* t, uint32_t level0_rays, uint32_t depth, uint32_t reset) {
     const uint32_t k = threadIdx.x;  // one wave; lane k owns shards k, k + 64, ...
-    unsigned long long rays[kLevels] = {}, hits[kLevels] = {}, nodes = 0, patterned = 0, transparent = 0;
+    unsigned long long rays[kLevels] = {}, hits[kLevels] = {}, nodes = 0, patterned = 0, transparent = 0, dark = 0;
     unsigned long long ev[9] = {};  // StatLine's nine counts
     for (uint32_t sh = k; sh < kShards; sh += 64u) {
         ShardCounters* sc = &c->shard[sh];
@@ -242,6 +258,8 @@ __global__ void k_accumulate(Counters* c, Totals* t, uint32_t level0_rays, uint3
         patterned += static_cast<uint32_t>(sc->hit_kinds);
         transparent += sc->hit_kinds >> 32;
         sc->hit_kinds = 0ull;
+        dark += sc->dark;
+        sc->dark = 0u;
     }
     for (int off = 32; off > 0; off >>= 1) {
 #pragma unroll
@@ -252,6 +270,7 @@ __global__ void k_accumulate(Counters* c, Totals* t, uint32_t level0_rays, uint3
         nodes += __shfl_down(nodes, off);
         patterned += __shfl_down(patterned, off);
         transparent += __shfl_down(transparent, off);
+        dark += __shfl_down(dark, off);
 #pragma unroll
         for (int e = 0; e < 9; ++e) ev[e] += __shfl_down(ev[e], off);
     }
@@ -267,6 +286,7 @@ __global__ void k_accumulate(Counters* c, Totals* t, uint32_t level0_rays, uint3
         t->nodes += nodes;
         t->hits_patterned += patterned;
         t->hits_transparent += transparent;
+        t->shadow_skipped += dark;
     }
 }
 
@@ -348,6 +368,9 @@ static_assert(kStaticScratchBytes <= (32u << 20), "the static work set is docume
 
 static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
 
+// A factor of lighting()'s ambient term that can never make it -0 or NaN: finite, not negative, not -0.
+inline bool plain_factor(float x) { return std::isfinite(x) && !std::signbit(x); }
+
 struct rtx_scene {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -373,6 +396,9 @@ struct rtx_scene {
     bool canon = false;      // the scene keeps w == 1 / w == 0 exact (see dot<C>)
     bool two_children = false;  // some material is reflective AND transparent: a hit may spawn two rays
     bool finite_schlick = true;  // every refractive index is finite and > 0: schlick() cannot return inf / NaN
+    bool plain_materials = true; // every material / pattern colour and ambient is finite and not negative (nor -0)
+    bool shadow_skip = true;     // ... and the light's intensity too: no ambient term can be -0 or NaN, so a hit with the
+                                 // light behind it is `ambient` shadowed or not
     float light_position[4];
     float light_intensity[3];
 
@@ -808,6 +834,7 @@ void fill_scene_params(const rtx_scene* s, P& p, uint32_t depth) {
     p.bvh_tris = s->d_bvh_tris;
     p.has_bvh = s->n_bvh_nodes ? 1u : 0u;
     p.finite_schlick = s->finite_schlick ? 1u : 0u;
+    p.shadow_skip = s->shadow_skip ? 1u : 0u;  // render_impl_t clears it for rtx_opts.all_shadows
     p.materials = s->d_materials;
     p.patterns = s->d_patterns;
     p.n_nodes = s->n_nodes;
@@ -1020,6 +1047,10 @@ int render_impl_t(rtx_scene* s, const rtx_camera* cam, const rtx_opts* opts, flo
         static const bool off = getenv("RTX_NO_CANON") != nullptr;  // A/B switch for experiments
         p.canon = (s->canon && cam_canon && !off && !(opts && opts->full_w)) ? 1u : 0u;
     }
+    {
+        static const bool off = getenv("RTX_NO_SHADOW_SKIP") != nullptr;  // A/B switch for experiments
+        if (off || (opts && opts->all_shadows)) p.shadow_skip = 0u;
+    }
     if (opts && opts->containers > RTX_CONTAINERS_BOOK) return fail(RTX_E_INVALID, "containers %u: RTX_CONTAINERS_V1 or RTX_CONTAINERS_BOOK", opts->containers);
     if (opts && opts->containers == RTX_CONTAINERS_BOOK && s->track_n1) {
         // every level of the frame runs the plain variants (see book_kernel): one ray format, no LDS tables
@@ -1107,6 +1138,7 @@ int render_impl_t(rtx_scene* s, const rtx_camera* cam, const rtx_opts* opts, flo
             t.nodes += part[l].nodes;
             t.hits_patterned += part[l].hits_patterned;
             t.hits_transparent += part[l].hits_transparent;
+            t.shadow_skipped += part[l].shadow_skipped;
             t.bvh_box += part[l].bvh_box;
             t.bvh_tri += part[l].bvh_tri;
             t.gate += part[l].gate;
@@ -1126,6 +1158,7 @@ int render_impl_t(rtx_scene* s, const rtx_camera* cam, const rtx_opts* opts, flo
         stats->nodes = t.nodes;
         stats->hits_patterned = t.hits_patterned;
         stats->hits_transparent = t.hits_transparent;
+        stats->shadow_rays_skipped = t.shadow_skipped;
         stats->bvh_box_tests = t.bvh_box;
         stats->bvh_triangle_tests = t.bvh_tri;
         stats->gate_tests = t.gate;
@@ -1222,6 +1255,19 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out) {
         if (m.transparency != 0.0f || m.reflective != 0.0f) s->can_spawn = true;
         if (m.transparency != 0.0f && m.reflective != 0.0f) s->two_children = true;
         if (!(m.refractive_index > 0.0f && m.refractive_index < INFINITY)) s->finite_schlick = false;
+    }
+    {
+        // lighting()'s ambient term is (colour * intensity) * ambient per channel; with every factor finite
+        // and not negative (no -0 either) it is never -0 and never NaN, and `ambient + 0 + 0` is `ambient`.
+        bool ok = true;
+        for (uint32_t i = 0; i < desc->n_materials; ++i) {
+            const rtx_material& m = desc->materials[i];
+            ok = ok && plain_factor(m.ambient) && plain_factor(m.color[0]) && plain_factor(m.color[1]) && plain_factor(m.color[2]);
+        }
+        for (uint32_t i = 0; i < desc->n_patterns; ++i)
+            for (int k = 0; k < 3; ++k) ok = ok && plain_factor(desc->patterns[i].a[k]) && plain_factor(desc->patterns[i].b[k]);
+        s->plain_materials = ok;
+        s->shadow_skip = ok && plain_factor(desc->light_intensity[0]) && plain_factor(desc->light_intensity[1]) && plain_factor(desc->light_intensity[2]);
     }
 
     auto upload = [&](void** dst, const void* src, size_t bytes) -> hipError_t {
@@ -1398,6 +1444,7 @@ int rtx_scene_refit(rtx_scene* s, const rtx_scene_desc* desc) {
     }
     std::memcpy(s->light_position, desc->light_position, sizeof s->light_position);
     std::memcpy(s->light_intensity, desc->light_intensity, sizeof s->light_intensity);
+    s->shadow_skip = s->plain_materials && plain_factor(desc->light_intensity[0]) && plain_factor(desc->light_intensity[1]) && plain_factor(desc->light_intensity[2]);
     HIP_TRY(hipMemcpy(s->d_shapes, shapes.data(), sizeof(rtx_shape) * shapes.size(), hipMemcpyHostToDevice));
     const std::vector<HitRec> hitrecs = build_hitrecs(shapes);
     HIP_TRY(hipMemcpy(s->d_hitrecs, hitrecs.data(), sizeof(HitRec) * hitrecs.size(), hipMemcpyHostToDevice));

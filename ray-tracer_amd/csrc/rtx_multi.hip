@@ -114,6 +114,7 @@ void add_stats(rtx_stats& a, const rtx_stats& b) {
         a.level_hits[k] += b.level_hits[k];
         a.shape_tests[k] += b.shape_tests[k];
     }
+    a.shadow_rays_skipped += b.shadow_rays_skipped;
     a.rows_rendered += b.rows_rendered;
     a.kernel_flags |= b.kernel_flags;
 }

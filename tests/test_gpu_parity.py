@@ -639,6 +639,56 @@ def test_two_lanes_equal_one_lane():
     scene.close()
 
 
+@pytest.mark.parametrize("name,w,h", [("glass_spheres", 320, 200), ("cylinder_world", 320, 200), ("reflective_floor", 320, 200), ("striped_scene", 256, 160)])
+def test_skipped_shadow_rays_cannot_be_seen(name, w, h):
+    # A hit with the light behind its surface returns the ambient term shadowed or not (src/material.zig:72-79):
+    # its isShadowed call is counted but not traversed.  The canvas must be the same BITS (+0 / -0 included) as
+    # with every shadow ray traversed (rtx_opts.all_shadows), and both must be the oracle's.
+    s = rta.Sample(name, w, h)
+    scene = rta.Scene(s.world)
+    fast, st_fast = scene.render(s.camera)
+    full, st_full = scene.render(s.camera, all_shadows=True)
+    assert fast.tobytes() == full.tobytes()
+    assert (st_fast.rays_primary, st_fast.rays_shadow, st_fast.rays_secondary) == (st_full.rays_primary, st_full.rays_shadow, st_full.rays_secondary)
+    assert list(st_fast.level_hits) == list(st_full.level_hits)
+    assert 0 < st_fast.shadow_rays_skipped < st_fast.rays_shadow and st_full.shadow_rays_skipped == 0
+    ref, counts = o.render(s.camera, s.world)
+    compare(fast, ref, name + " (shadow skip)")
+    assert st_fast.rays_shadow == counts.shadow
+    scene.close()
+
+
+def test_shadow_skip_is_off_where_ambient_could_be_negative_zero():
+    # ambient + 0 + 0 is not ambient when ambient is -0: a scene with a negative (or -0, or non-finite) colour,
+    # ambient or light intensity traverses every shadow ray.
+    def world(tweak):
+        ball = st.Sphere(st.default_attrs())
+        floor = st.Plane(st.default_attrs())
+        floor.common_attrs.transform = su.translation(0, -1, 0)
+        tweak(ball.common_attrs.material)
+        return st.make_world([-10, 10, -10, 1], [1, 1, 1], spheres=[ball], planes=[floor])
+
+    def neg_colour(m):
+        m.color[:] = [-0.5, 0.2, 0.0]
+
+    def neg_zero_ambient(m):
+        m.ambient = -0.0
+
+    def plain(m):
+        m.color[:] = [0.5, 0.2, 0.0]
+
+    cam = su.default_camera(160, 96)
+    for tweak, skips in ((neg_colour, False), (neg_zero_ambient, False), (plain, True)):
+        w, keep = world(tweak)
+        scene = rta.Scene(w)
+        gpu, stats = scene.render(cam)
+        ref, counts = o.render(cam, w)
+        assert gpu.view(np.uint32).tobytes() == ref.view(np.uint32).tobytes(), tweak.__name__  # -0 must stay -0
+        assert stats.rays_shadow == counts.shadow
+        assert (stats.shadow_rays_skipped > 0) == skips, tweak.__name__
+        scene.close()
+
+
 def test_scene_lifecycle_returns_device_memory():
     import torch
 
