@@ -29,3 +29,6 @@ iters = sum(st.level_rays) / 64.0
 print(name, w, h, "ray-wave iterations ~%.0f, fenced cycles per iteration %.0f" % (iters, tot / iters))
 for n, v in zip(names, buf[:8]):
     print("  %-26s %5.1f%%  %8.0f cycles/iteration" % (n, 100.0 * v / tot, v / iters))
+for which, base in (("closest", 8), ("shadow", 12)):
+    for n, v in zip(("gate tests", "linear shapes", "BVH walk", "node record fetch"), buf[base:base + 4]):
+        print("    %-8s %-14s %5.1f%%  %8.0f cycles/iteration" % (which, n, 100.0 * v / tot, v / iters))
