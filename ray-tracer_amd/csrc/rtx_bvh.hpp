@@ -25,6 +25,9 @@ constexpr uint32_t kNoLeaf = 0xFFFFFFFFu;
 #ifndef RTX_LEAF_TRIS
 #define RTX_LEAF_TRIS 4
 #endif
+#ifndef RTX_SAH_BINS
+#define RTX_SAH_BINS 32
+#endif
 #ifndef RTX_SAH_AXES
 #define RTX_SAH_AXES 3
 #endif
@@ -207,8 +210,8 @@ struct Builder {
             if (n <= 7) return make_leaf(box, lo, hi);
             mid = lo + n / 2;
         } else {
-            // Binned SAH: the cheapest of the 15 splits of each axis (RTX_SAH_AXES = 1: widest centroid axis only).
-            constexpr int kBins = 16;
+            // Binned SAH: the cheapest of the kBins - 1 splits of each axis (RTX_SAH_AXES = 1: widest centroid axis only).
+            constexpr int kBins = RTX_SAH_BINS;
             double best = INFINITY;
             int best_split = -1, best_axis = axis;
             for (int pass = 0; pass < RTX_SAH_AXES; ++pass) {
