@@ -22,6 +22,7 @@ h = int(sys.argv[3]) if len(sys.argv) > 3 else 1080
 frames = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 batch = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 no_bvh = os.environ.get("RTX_NO_BVH") == "1"
+f64 = os.environ.get("RTX_F64") == "1"  # rtx_opts.real = RTX_REAL_F64 for every frame
 world, cam, keep = load(name, w, h)
 scene = rta.Scene(world)
 print("shapes", scene.n_shapes)
@@ -30,17 +31,17 @@ if os.environ.get("RTX_PROFILE", "1") == "0":
     rgb = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda")
     stream = torch.cuda.Stream()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    scene.render_device(cam, rgb.data_ptr(), None, stream=stream.cuda_stream, batch_pixels=batch, no_bvh=no_bvh)  # warm-up, allocations
+    scene.render_device(cam, rgb.data_ptr(), None, stream=stream.cuda_stream, batch_pixels=batch, no_bvh=no_bvh, f64=f64)  # warm-up, allocations
     a.record(stream)
     for i in range(frames):
-        scene.render_device(cam, rgb.data_ptr(), None, stream=stream.cuda_stream, batch_pixels=batch, no_bvh=no_bvh)
+        scene.render_device(cam, rgb.data_ptr(), None, stream=stream.cuda_stream, batch_pixels=batch, no_bvh=no_bvh, f64=f64)
     b.record(stream)
     torch.cuda.synchronize()
     ms_frame = a.elapsed_time(b) / frames
-    canvas, st = scene.render(cam, batch_pixels=batch, no_bvh=no_bvh)
+    canvas, st = scene.render(cam, batch_pixels=batch, no_bvh=no_bvh, f64=f64)
 else:
     for i in range(frames):
-        canvas, st = scene.render(cam, batch_pixels=batch, profile=True, no_bvh=no_bvh)
+        canvas, st = scene.render(cam, batch_pixels=batch, profile=True, no_bvh=no_bvh, f64=f64)
 if os.environ.get("RTX_SAVE"):
     import numpy as np
 
