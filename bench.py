@@ -99,6 +99,20 @@ def measured_traffic():
     return None, None
 
 
+def measured_flops():
+    """Hardware flop slots (64 x (ADD + MUL + 2 FMA + TRANS) f32 wave-instructions) of one headline frame's
+    k_trace_shade launches from the newest committed counter pass (profiles/r*_flops.json, tools/flop_counters.sh):
+    the cross-check of the algorithmic count.  (None, None) if none has been committed."""
+    import glob
+
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_flops.json")), reverse=True):
+        with open(path) as f:
+            d = json.load(f)
+        if d.get("frame") == "composite %dx%d" % (WIDTH, HEIGHT):
+            return d["f32"], os.path.relpath(path, ROOT)
+    return None, None
+
+
 def usable_threads():
     """Hardware threads this process may use: the affinity mask, capped by the box's own hint
     (OMP_NUM_THREADS is set to the CPU share of a one-GPU box; os.cpu_count() shows the whole machine)."""
@@ -348,6 +362,7 @@ def main():
         flops_per_launch = flops_frame * profiled_steps / max(launches, 1)
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         traffic, traffic_src = measured_traffic() if n == 1 else (None, None)  # the PMC pass is of whole frames
+        hw_flops, hw_flops_src = measured_flops() if n == 1 else (None, None)
         frames_per_step = 1 if n == 1 or split else n
         out = {
             "metric": "Mrays/s (primary+shadow+secondary)",
@@ -381,6 +396,8 @@ def main():
                 "frac": achieved / VALU_PEAK_FMA_TFLOPS,
                 "frac_of_unfused_issue_rate": achieved / VALU_PEAK_UNFUSED_TFLOPS, "frac_of_spec_peak": achieved / VALU_PEAK_SPEC_TFLOPS,
                 "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
+                "hw_flop_counters": ({"flop_slots_per_frame": hw_flops["flop_slots"], "flops_on_active_lanes_per_frame": hw_flops["flops_active_lanes"],
+                                      "lanes_active": hw_flops["lanes_active"], "source": hw_flops_src} if hw_flops else None),
                 "flops_per_launch": flops_per_launch, "flops_per_frame": flops_frame, "avg_launch_ms": avg_ms, "launches": launches,
                 "share_of_step": (prof.ms_trace_shade / profiled_steps) / (dt / args.steps * 1e3) if dt > 0 and profiled_steps else None,
                 "events": {"shape_tests": list(stats.shape_tests), "gate_tests": stats.gate_tests, "bvh_box_tests": stats.bvh_box_tests,
