@@ -104,13 +104,14 @@ constexpr uint32_t kShards = RTX_SHARDS;  // a multiple of 64, at most 256 (leve
 static_assert(kShards % 64u == 0u && kShards <= 256u, "see k_trace_shade and k_accumulate");
 
 struct ShardCounters {  // one 128-byte line per shard
-    // per level d: low 32 bits = reflected rays queued for level d + 1, high 32 bits = interior nodes at d
+    // per level d: low 32 bits = reflected rays queued for level d + 1, high 32 bits = interior nodes at d with ONE child
+    // (allocated from the bottom of the shard's node region; folded at delivery, never combined)
     unsigned long long alloc[kLevels];
+    // per level d: low 32 bits = refracted rays queued for level d + 1 (their own region, from the top), high 32 bits =
+    // interior nodes at d with TWO children (allocated from the top of the node region: all that k_combine walks)
+    unsigned long long refr[kLevels];
     unsigned long long hit_kinds;  // low 32: hits on patterned materials, high 32: on transparent ones
     uint32_t hits[kLevels];        // hits at level d == isShadowed calls
-    uint32_t refr[kLevels];        // per level d: refracted rays queued for level d + 1 (their own region)
-    uint32_t dark;                 // hits with the light behind the surface whose isShadowed call was not traversed
-    uint32_t pad[32 - 2 * kLevels - 2 - kLevels - kLevels - 1];
 };
 static_assert(sizeof(ShardCounters) == 128, "one cache line per shard");
 
@@ -129,7 +130,8 @@ struct StatLine {
     unsigned long long bvh_tri;   // triangle tests inside BVH leaves
     unsigned long long gate;      // group-gate box tests (bnd.intersect, src/group.zig:58)
     unsigned long long shape[6];  // linear shape tests by RTX_* type, lanes that actually test
-    unsigned long long pad[16 - 9];
+    unsigned long long dark;      // hits with the light behind the surface whose isShadowed call was not traversed (every kernel)
+    unsigned long long pad[16 - 10];
 };
 static_assert(sizeof(StatLine) == 128, "one cache line per shard");
 
@@ -234,32 +236,31 @@ using namespace f32;  // the host side below speaks f32 unless it says f64::
 // one wave, lane k owns shard k.  `reset` starts a new frame's totals.
 __global__ void k_accumulate(Counters* c, Totals* t, uint32_t level0_rays, uint32_t depth, uint32_t reset) {
     const uint32_t k = threadIdx.x;  // one wave; lane k owns shards k, k + 64, ...
-    unsigned long long rays[kLevels] = {}, hits[kLevels] = {}, nodes = 0, patterned = 0, transparent = 0, dark = 0;
-    unsigned long long ev[9] = {};  // StatLine's nine counts
+    unsigned long long rays[kLevels] = {}, hits[kLevels] = {}, nodes = 0, patterned = 0, transparent = 0;
+    unsigned long long ev[10] = {};  // StatLine's ten counts
     for (uint32_t sh = k; sh < kShards; sh += 64u) {
         ShardCounters* sc = &c->shard[sh];
         unsigned long long* sl = reinterpret_cast<unsigned long long*>(&c->stats[sh]);
 #pragma unroll
-        for (int e = 0; e < 9; ++e) {
+        for (int e = 0; e < 10; ++e) {
             ev[e] += sl[e];
             sl[e] = 0ull;
         }
 #pragma unroll
         for (int l = 0; l < kLevels; ++l) {
             const unsigned long long a = sc->alloc[l];
-            rays[l] += (static_cast<uint32_t>(l) <= depth) ? static_cast<unsigned long long>(static_cast<uint32_t>(a)) + sc->refr[l] : 0ull;
-            nodes += (static_cast<uint32_t>(l) <= depth) ? (a >> 32) : 0ull;
+            const unsigned long long r = sc->refr[l];
+            rays[l] += (static_cast<uint32_t>(l) <= depth) ? static_cast<unsigned long long>(static_cast<uint32_t>(a)) + static_cast<uint32_t>(r) : 0ull;
+            nodes += (static_cast<uint32_t>(l) <= depth) ? (a >> 32) + (r >> 32) : 0ull;
             hits[l] += sc->hits[l];
             sc->alloc[l] = 0ull;
             sc->hits[l] = 0u;
-            sc->refr[l] = 0u;
+            sc->refr[l] = 0ull;
             c->claims[sh].claim[l] = 0u;
         }
         patterned += static_cast<uint32_t>(sc->hit_kinds);
         transparent += sc->hit_kinds >> 32;
         sc->hit_kinds = 0ull;
-        dark += sc->dark;
-        sc->dark = 0u;
     }
     for (int off = 32; off > 0; off >>= 1) {
 #pragma unroll
@@ -270,9 +271,8 @@ __global__ void k_accumulate(Counters* c, Totals* t, uint32_t level0_rays, uint3
         nodes += __shfl_down(nodes, off);
         patterned += __shfl_down(patterned, off);
         transparent += __shfl_down(transparent, off);
-        dark += __shfl_down(dark, off);
 #pragma unroll
-        for (int e = 0; e < 9; ++e) ev[e] += __shfl_down(ev[e], off);
+        for (int e = 0; e < 10; ++e) ev[e] += __shfl_down(ev[e], off);
     }
     if (k == 0) {
         if (reset) *t = Totals{};
@@ -286,7 +286,7 @@ __global__ void k_accumulate(Counters* c, Totals* t, uint32_t level0_rays, uint3
         t->nodes += nodes;
         t->hits_patterned += patterned;
         t->hits_transparent += transparent;
-        t->shadow_skipped += dark;
+        t->shadow_skipped += ev[9];
     }
 }
 
