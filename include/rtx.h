@@ -234,9 +234,15 @@ void rtx_scene_destroy(rtx_scene* scene);
  * The same scene after its shapes moved (new vertices, transforms, boxes, light; materials and patterns stay
  * as created: they decide the work buffers' layout):
  * `desc` must have the structure the scene was created with (same counts, same node ranges, every shape
- * of the same type).  Records are uploaded again and the device-built trees are refitted — boxes
+ * of the same type AND with the same material index: which materials are in use decided at creation whether
+ * hits can spawn one or two child rays, and the ray queues are sized for that — a changed index is rejected
+ * with RTX_E_INVALID).  Records are uploaded again and the device-built trees are refitted — boxes
  * recomputed bottom-up over the unchanged topology — instead of rebuilt.  Needs RTX_SCENE_BVH_DEVICE at
- * creation.  No counterpart in the reference (its groups are rebuilt by value every frame).  Blocking.
+ * creation.  No counterpart in the reference (its groups are rebuilt by value every frame).
+ * Blocking, and it waits for the whole device first (hipDeviceSynchronize): frames still in flight on any
+ * stream finish on the old records.  A descriptor that cannot be refitted (structure changed, a triangle that
+ * cannot be bounded) is rejected before any device record changes; if an error strikes later (a HIP failure
+ * half way), the scene is marked unusable and every later call on it fails until it is destroyed.
  */
 int rtx_scene_refit(rtx_scene* scene, const rtx_scene_desc* desc);
 
@@ -292,7 +298,9 @@ uint32_t rtx_static_max_width(void);
  *   rtx_multi_render         into caller-owned HOST canvases (f32 and / or u8, either may be NULL),
  *                            every GPU copying over its own PCIe link;
  *   rtx_multi_render_device  into canvases on the FIRST device of the list, peers copying over
- *                            their own xGMI link (hipMemcpyPeerAsync) — the canvas exchange.
+ *                            their own xGMI link (one strided hipMemcpy2DAsync per set and canvas; peer
+ *                            access is enabled in rtx_multi_create) — the canvas exchange.
+ * The calling thread's current device is restored before each of these returns.
  * Both block until the frame is complete.  The canvas equals rtx_render's bit for bit for any
  * device list and chunk count.  `opts` as for rtx_render, except that strip_count / compact_rows
  * must be zero (the strips are this call's) and profile is ignored; `stats` (may be NULL) sums the
@@ -302,6 +310,9 @@ typedef struct rtx_multi rtx_multi;
 int rtx_multi_create(const rtx_scene_desc* desc, const int* devices, uint32_t n_devices, rtx_multi** out);
 void rtx_multi_destroy(rtx_multi* multi);
 uint32_t rtx_multi_device_count(const rtx_multi* multi);
+/* Directed peer-access links between the first device and the others that rtx_multi_create found switched on or
+ * switched on itself (hipDeviceEnablePeerAccess): 2 * (distinct peers) when every peer can reach the root directly. */
+uint32_t rtx_multi_peer_links(const rtx_multi* multi);
 int rtx_multi_render(rtx_multi* multi, const rtx_camera* cam, const rtx_opts* opts, uint32_t chunks_per_gpu,
                      float* rgb_out, uint8_t* rgb8_out, rtx_stats* stats);
 int rtx_multi_render_device(rtx_multi* multi, const rtx_camera* cam, const rtx_opts* opts, uint32_t chunks_per_gpu,

@@ -102,6 +102,7 @@ _SIGNATURES = [
     ("rtx_multi_create", C.c_int, [P(RtxSceneDesc), P(C.c_int), u32, P(C.c_void_p)]),
     ("rtx_multi_destroy", None, [C.c_void_p]),
     ("rtx_multi_device_count", u32, [C.c_void_p]),
+    ("rtx_multi_peer_links", u32, [C.c_void_p]),
     ("rtx_multi_render", C.c_int, [C.c_void_p, P(RtxCamera), P(RtxOpts), u32, P(f32), P(C.c_uint8), P(RtxStats)]),
     ("rtx_multi_render_device", C.c_int, [C.c_void_p, P(RtxCamera), P(RtxOpts), u32, C.c_void_p, C.c_void_p, P(RtxStats)]),
     ("rtx_strip_row_map", C.c_int, [P(RtxCamera), P(RtxOpts), P(u32), u32, P(u32)]),
@@ -412,6 +413,7 @@ class MultiScene:
         _check(lib().rtx_multi_create(C.byref(flat.desc), arr, len(devices) if devices else 0, C.byref(h)))
         self.handle = h
         self.n_devices = lib().rtx_multi_device_count(h)
+        self.peer_links = lib().rtx_multi_peer_links(h)
 
     def close(self):
         if getattr(self, "handle", None) and lib is not None:

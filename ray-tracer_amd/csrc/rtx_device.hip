@@ -207,6 +207,8 @@ RTX_HD float r_min(float a, float b) { return fminf(a, b); }
 RTX_HD double r_min(double a, double b) { return fmin(a, b); }
 RTX_HD float r_fma(float a, float b, float c) { return fmaf(a, b, c); }
 RTX_HD double r_fma(double a, double b, double c) { return fma(a, b, c); }
+RTX_HD bool r_signbit(float x) { return (__builtin_bit_cast(uint32_t, x) >> 31) != 0u; }
+RTX_HD bool r_signbit(double x) { return (__builtin_bit_cast(uint64_t, x) >> 63) != 0ull; }
 RTX_HD float r_floor(float x) { return floorf(x); }
 RTX_HD double r_floor(double x) { return floor(x); }
 RTX_HD float r_trunc(float x) { return truncf(x); }
@@ -384,13 +386,16 @@ struct rtx_scene {
     struct DeviceTree {  // a tree built on the device (RTX_SCENE_BVH_DEVICE), kept for rtx_scene_refit
         rtx_lbvh::Tree* tree;
         uint32_t node_base, tri_base;
+        std::vector<uint32_t> shapes;  // the triangles it holds (rtx_scene_refit checks them on the host before it uploads anything)
     };
     std::vector<DeviceTree> device_trees;
     std::vector<rtx_node> h_nodes;  // the gates as uploaded (BVH links included): refit re-uploads them with new boxes
     bool host_trees = false;        // some tree came from the host builder (such a scene cannot be refitted)
+    bool broken = false;            // a refit failed after it had started to overwrite device records: every render call fails
     rtx_material* d_materials = nullptr;
     rtx_pattern* d_patterns = nullptr;
     uint32_t n_shapes = 0, n_nodes = 0, n_materials = 0, n_patterns = 0;
+    uint32_t n_nodes_walk = 0;  // nodes in d_nodes: the gates with something to test (walkable_nodes); d_nodes_linear holds all n_nodes
     bool track_n1 = false;   // some material is transparent: n1/n2 matter
     bool can_spawn = false;  // some material is reflective or transparent: child rays exist
     bool canon = false;      // the scene keeps w == 1 / w == 0 exact (see dot<C>)
@@ -704,6 +709,7 @@ int validate_desc(const rtx_scene_desc* d) {
 struct BvhInfo {
     uint32_t root, walk_node;
     std::vector<uint32_t> shapes;
+    std::vector<uint32_t> members;  // on_device classes: the nodes whose trailing triangle runs the tree takes over
 };
 
 // Library-side derived data: identity flags on the shapes and the triangle BVHs.
@@ -785,7 +791,7 @@ void build_bvhs(std::vector<rtx_shape>& shapes, std::vector<rtx_node>& nodes, st
             }
             if (hittable.size() >= rtx_bvh::kMinTris) {
                 for (size_t k = 0; k < members.size(); ++k) nodes[members[k]].reserved[1] = n_lin[k];
-                on_device->push_back(BvhInfo{0u, members.back(), hittable});
+                on_device->push_back(BvhInfo{0u, members.back(), hittable, members});
                 continue;
             }
         }
@@ -793,8 +799,34 @@ void build_bvhs(std::vector<rtx_shape>& shapes, std::vector<rtx_node>& nodes, st
         if (root == rtx_bvh::kNoLeaf) continue;
         for (size_t k = 0; k < members.size(); ++k) nodes[members[k]].reserved[1] = n_lin[k];
         nodes[members.back()].reserved[0] = root + 1;
-        if (info) info->push_back(BvhInfo{root, members.back(), tris});
+        if (info) info->push_back(BvhInfo{root, members.back(), tris, {}});
     }
+}
+
+// The gates as the kernels walk them: a node that has nothing to test — no box of its own, no linearly tested
+// shape, no tree walked at it (an OBJ file's named sub-groups whose triangles sit in their class's tree, or an
+// empty group) — costs every traversal of every wave a record fetch and a loop turn for nothing, so it is
+// left out and the skip links are renumbered.  (A lane parked by a box wakes at `skip`, the first node after
+// that box's subtree: the first KEPT node at or after it serves the same.)
+std::vector<rtx_node> walkable_nodes(const std::vector<rtx_node>& nodes) {
+    const uint32_t nn = (uint32_t)nodes.size();
+    std::vector<uint32_t> new_index(nn + 1u, 0u);  // new index of the first kept node at or after old index i
+    std::vector<rtx_node> out;
+    out.reserve(nn);
+    std::vector<bool> keep(nn, true);
+    static const bool keep_all = getenv("RTX_ALL_NODES") != nullptr;  // A/B switch for experiments
+    for (uint32_t i = 1; i < nn; ++i) keep[i] = keep_all || nodes[i].has_bounds || nodes[i].reserved[0] != 0u || nodes[i].reserved[1] != 0u;
+    uint32_t kept = 0;
+    for (uint32_t i = 0; i < nn; ++i) kept += keep[i] ? 1u : 0u;
+    new_index[nn] = kept;
+    for (uint32_t i = nn; i-- > 0;) new_index[i] = keep[i] ? new_index[i + 1] - 1u : new_index[i + 1];
+    for (uint32_t i = 0; i < nn; ++i) {
+        if (!keep[i]) continue;
+        rtx_node n = nodes[i];
+        n.skip = new_index[n.skip];
+        out.push_back(n);
+    }
+    return out;
 }
 
 // The 16-byte hit records of the (library-flagged) shapes: see HitRec.
@@ -837,7 +869,7 @@ void fill_scene_params(const rtx_scene* s, P& p, uint32_t depth) {
     p.shadow_skip = s->shadow_skip ? 1u : 0u;  // render_impl_t clears it for rtx_opts.all_shadows
     p.materials = s->d_materials;
     p.patterns = s->d_patterns;
-    p.n_nodes = s->n_nodes;
+    p.n_nodes = s->n_nodes_walk;
     p.n_shapes = s->n_shapes;
     p.n_materials = s->n_materials;
     p.n_patterns = s->n_patterns;
@@ -980,6 +1012,7 @@ int render_impl_t(rtx_scene* s, const rtx_camera* cam, const rtx_opts* opts, flo
     if (depth > kMaxDepth) return fail(RTX_E_INVALID, "depth %u exceeds ray_depth_limit %d", depth, kMaxDepth);
     if (opts && opts->strip_count > 1 && opts->strip_index >= opts->strip_count)
         return fail(RTX_E_INVALID, "strip_index %u >= strip_count %u", opts->strip_index, opts->strip_count);
+    if (s->broken) return fail(RTX_E_INVALID, "the scene is inconsistent after a failed rtx_scene_refit: destroy it");
     HIP_TRY(hipSetDevice(s->device));
     (void)hipGetLastError();  // an error some earlier, unrelated HIP call of this thread left behind is not this frame's
 
@@ -1073,6 +1106,7 @@ int render_impl_t(rtx_scene* s, const rtx_camera* cam, const rtx_opts* opts, flo
     if (fixed) fixed->counters_dirty = true;  // the array is shared by every scene on this GPU and keeps the last call's contents
     if (opts && opts->no_bvh) {
         p.nodes = s->d_nodes_linear;
+        p.n_nodes = s->n_nodes;
         p.has_bvh = 0;
     }
     std::memcpy(p.cam_inv, cam->inverse_transform, sizeof p.cam_inv);
@@ -1329,9 +1363,15 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out) {
             rtx_lbvh::Tree* tree = nullptr;
             uint32_t per_layout = 0;
             const int trc = rtx_lbvh::plan(s->d_shapes, c.shapes.data(), (uint32_t)c.shapes.size(), s->stream, &tree, &per_layout, err);
+            if (trc == rtx_lbvh::kUnboundable) {
+                // The host builder leaves a run with an unboundable triangle on the linear path (rtx_bvh::build_list
+                // returns kNoLeaf and build_bvhs skips the class): same scene, same canvas, whichever builder was asked for.
+                for (uint32_t member : c.members) nodes[member].reserved[1] = nodes[member].n_shapes;
+                continue;
+            }
             if (trc) return bail(fail(trc == -3 ? RTX_E_HIP : RTX_E_INVALID, "device BVH build: %s", err.c_str()));
             lap("device tree: plan");
-            s->device_trees.push_back(rtx_scene::DeviceTree{tree, (uint32_t)total_nodes, (uint32_t)total_tris});
+            s->device_trees.push_back(rtx_scene::DeviceTree{tree, (uint32_t)total_nodes, (uint32_t)total_tris, c.shapes});
             nodes[c.walk_node].reserved[0] = (uint32_t)total_nodes + 1u;
             total_nodes += (size_t)per_layout * rtx_bvh::kLayouts;
             total_tris += c.shapes.size();
@@ -1351,7 +1391,11 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out) {
     }
     lap("tree upload");
     s->h_nodes = nodes;
-    HIP_TRY_S(upload((void**)&s->d_nodes, nodes.data(), sizeof(rtx_node) * nodes.size()));
+    {
+        const std::vector<rtx_node> walk = walkable_nodes(nodes);
+        s->n_nodes_walk = (uint32_t)walk.size();
+        HIP_TRY_S(upload((void**)&s->d_nodes, walk.data(), sizeof(rtx_node) * walk.size()));
+    }
     HIP_TRY_S(upload((void**)&s->d_nodes_linear, linear.data(), sizeof(rtx_node) * linear.size()));
     HIP_TRY_S(upload((void**)&s->d_materials, desc->materials, sizeof(rtx_material) * desc->n_materials));
     HIP_TRY_S(upload((void**)&s->d_patterns, desc->patterns, sizeof(rtx_pattern) * desc->n_patterns));
@@ -1411,6 +1455,7 @@ void rtx_scene_destroy(rtx_scene* s) {
 
 int rtx_scene_refit(rtx_scene* s, const rtx_scene_desc* desc) {
     if (!s) return fail(RTX_E_INVALID, "scene is NULL");
+    if (s->broken) return fail(RTX_E_INVALID, "the scene is inconsistent after a failed rtx_scene_refit: destroy it");
     int rc = validate_desc(desc);
     if (rc) return rc;
     if (s->host_trees) return fail(RTX_E_INVALID, "rtx_scene_refit needs a scene whose trees were built on the device (RTX_SCENE_BVH_DEVICE)");
@@ -1422,10 +1467,14 @@ int rtx_scene_refit(rtx_scene* s, const rtx_scene_desc* desc) {
             return fail(RTX_E_INVALID, "rtx_scene_refit: node %u changed its structure", i);
     }
     HIP_TRY(hipSetDevice(s->device));
-    HIP_TRY(hipStreamSynchronize(s->stream));
+    // Frames may be in flight on any stream of the device (caller streams, lane streams: all non-blocking, so
+    // nothing orders them against the copies below): wait for all of them before a record changes.
+    HIP_TRY(hipDeviceSynchronize());
     std::vector<rtx_shape> shapes(desc->shapes, desc->shapes + desc->n_shapes);
     prepare_shapes(shapes);
-    {   // what a tree holds may move, not change kind: a triangle stays a (hittable) triangle
+    {   // what a tree holds may move, not change kind: a triangle stays a (hittable) triangle.  Material indices stay
+        // too: track_n1 / can_spawn / two_children / finite_schlick — and with them the sizes of the ray queues and
+        // the ray-tree node regions — were fixed at creation from the materials the shapes referenced then.
         std::vector<rtx_shape> old(s->n_shapes);
         HIP_TRY(hipMemcpy(old.data(), s->d_shapes, sizeof(rtx_shape) * old.size(), hipMemcpyDeviceToHost));
         for (uint32_t i = 0; i < s->n_shapes; ++i) {
@@ -1433,8 +1482,34 @@ int rtx_scene_refit(rtx_scene* s, const rtx_scene_desc* desc) {
             const bool is_flat = shapes[i].e0[0] == 0.0f && shapes[i].e0[1] == 0.0f && shapes[i].e0[2] == 0.0f && shapes[i].e0[3] == 0.0f;
             if (old[i].type != shapes[i].type || (shapes[i].type == RTX_TRIANGLE && was_flat != is_flat))
                 return fail(RTX_E_INVALID, "rtx_scene_refit: shape %u changed its type (or became / stopped being degenerate)", i);
+            if (old[i].material != shapes[i].material)
+                return fail(RTX_E_INVALID, "rtx_scene_refit: shape %u changed its material index (%u -> %u); materials stay as created", i,
+                            old[i].material, shapes[i].material);
         }
     }
+    // The new records go to an array of their own first, and every tree is asked whether it can bound its triangles
+    // there: a refit that cannot succeed fails here, with the scene as it was.
+    rtx_shape* d_new = nullptr;
+    HIP_TRY(hipMalloc(&d_new, sizeof(rtx_shape) * (shapes.empty() ? 1 : shapes.size())));
+    std::string err;
+    {
+        hipError_t e = hipMemcpy(d_new, shapes.data(), sizeof(rtx_shape) * shapes.size(), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            (void)hipFree(d_new);
+            return fail(RTX_E_HIP, "rtx_scene_refit: shape upload: %s", hipGetErrorString(e));
+        }
+        for (const rtx_scene::DeviceTree& t : s->device_trees) {
+            const int trc = rtx_lbvh::check(t.tree, d_new, s->stream, err);
+            if (trc) {
+                (void)hipFree(d_new);
+                return fail(trc == -3 ? RTX_E_HIP : RTX_E_INVALID, "device BVH refit: %s", err.c_str());
+            }
+        }
+    }
+    // From here on device records change: an error leaves the scene unusable (s->broken) instead of half-updated.
+    s->broken = true;
+    (void)hipFree(s->d_shapes);
+    s->d_shapes = d_new;
     // the scene-wide switches follow the new records
     s->canon = desc->light_position[3] == 1.0f;
     for (const rtx_shape& sh : shapes) {
@@ -1445,14 +1520,16 @@ int rtx_scene_refit(rtx_scene* s, const rtx_scene_desc* desc) {
     std::memcpy(s->light_position, desc->light_position, sizeof s->light_position);
     std::memcpy(s->light_intensity, desc->light_intensity, sizeof s->light_intensity);
     s->shadow_skip = s->plain_materials && plain_factor(desc->light_intensity[0]) && plain_factor(desc->light_intensity[1]) && plain_factor(desc->light_intensity[2]);
-    HIP_TRY(hipMemcpy(s->d_shapes, shapes.data(), sizeof(rtx_shape) * shapes.size(), hipMemcpyHostToDevice));
     const std::vector<HitRec> hitrecs = build_hitrecs(shapes);
     HIP_TRY(hipMemcpy(s->d_hitrecs, hitrecs.data(), sizeof(HitRec) * hitrecs.size(), hipMemcpyHostToDevice));
     for (uint32_t i = 0; i < desc->n_nodes; ++i) {
         std::memcpy(s->h_nodes[i].bounds_min, desc->nodes[i].bounds_min, sizeof s->h_nodes[i].bounds_min);
         std::memcpy(s->h_nodes[i].bounds_max, desc->nodes[i].bounds_max, sizeof s->h_nodes[i].bounds_max);
     }
-    HIP_TRY(hipMemcpy(s->d_nodes, s->h_nodes.data(), sizeof(rtx_node) * s->h_nodes.size(), hipMemcpyHostToDevice));
+    {
+        const std::vector<rtx_node> walk = walkable_nodes(s->h_nodes);  // boxes change, the structure (and so the count) does not
+        HIP_TRY(hipMemcpy(s->d_nodes, walk.data(), sizeof(rtx_node) * walk.size(), hipMemcpyHostToDevice));
+    }
     {
         std::vector<rtx_node> linear = s->h_nodes;
         for (rtx_node& n : linear) {
@@ -1461,11 +1538,11 @@ int rtx_scene_refit(rtx_scene* s, const rtx_scene_desc* desc) {
         }
         HIP_TRY(hipMemcpy(s->d_nodes_linear, linear.data(), sizeof(rtx_node) * linear.size(), hipMemcpyHostToDevice));
     }
-    std::string err;
     for (const rtx_scene::DeviceTree& t : s->device_trees) {
         const int trc = rtx_lbvh::refit(t.tree, s->d_shapes, s->d_bvh_nodes, t.node_base, s->d_bvh_tris, t.tri_base, s->stream, err);
         if (trc) return fail(trc == -3 ? RTX_E_HIP : RTX_E_INVALID, "device BVH refit: %s", err.c_str());
     }
+    s->broken = false;
     return RTX_OK;
 }
 
@@ -1652,6 +1729,7 @@ int rtx_color_at(rtx_scene* s, const float* origins, const float* directions, ui
     if (depth == 0) depth = kMaxDepth;
     if (depth > kMaxDepth) return fail(RTX_E_INVALID, "depth %u exceeds ray_depth_limit %d", depth, kMaxDepth);
     if (n > (1u << 22)) return fail(RTX_E_INVALID, "at most %u rays per call", 1u << 22);
+    if (s->broken) return fail(RTX_E_INVALID, "the scene is inconsistent after a failed rtx_scene_refit: destroy it");
     HIP_TRY(hipSetDevice(s->device));
     // Canonical kernels need canonical rays too: origins with w == 1, directions with w == 0.
     bool canon = s->canon;

@@ -274,8 +274,9 @@ __global__ void k_emit(uint32_t n, Topology t, const float* box, const uint32_t*
         const uint32_t at = node_base + q * per_layout + idx[q];
         rtx_bvh::Node out;
         for (int k = 0; k < 3; ++k) {
-            out.bmin[k] = box[6ull * id + k];
-            out.bmax[k] = box[6ull * id + 3 + k];
+            const bool swap = RTX_NEARFAR && ((q >> k) & 1u);  // near / far planes for a ray of octant q (rtx_bvh::Node)
+            out.bmin[k] = box[6ull * id + (swap ? 3 : 0) + k];
+            out.bmax[k] = box[6ull * id + (swap ? 0 : 3) + k];
         }
         out.skip = at + esize[id];
         out.leaf = leaf ? (((tri_base + first) << 3) | cnt) : rtx_bvh::kNoLeaf;
@@ -349,7 +350,7 @@ int compute_bounds(Tree* t, const rtx_shape* d_shapes, hipStream_t st, bool with
     LB_TRY(hipStreamSynchronize(st));
     if (bad) {
         err = "a triangle cannot be bounded (singular transform or non-finite vertex)";
-        return -1;
+        return kUnboundable;
     }
     return 0;
 }
@@ -364,6 +365,8 @@ int run_bottom_up(Tree* t, hipStream_t st, std::string& err) {
 }
 
 }  // namespace
+
+int check(Tree* t, const rtx_shape* d_shapes, hipStream_t st, std::string& err) { return compute_bounds(t, d_shapes, st, false, err); }
 
 int plan(const rtx_shape* d_shapes, const uint32_t* h_indices, uint32_t n, hipStream_t st, Tree** out, uint32_t* n_nodes, std::string& err) {
     *out = nullptr;

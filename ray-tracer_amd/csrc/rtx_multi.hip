@@ -8,8 +8,9 @@
 // none is left — with more chunks than GPUs that is dynamic stealing: a GPU that finishes early takes
 // the next chunk — renders each with the ordinary single-GPU pipeline (rtx_render_device, compact
 // rows) and puts the rows where they belong: straight into the caller's host canvas over that GPU's
-// own PCIe link, or into a canvas on the first device with peer copies (hipMemcpyPeerAsync: each
-// peer's own xGMI link to the root, no ring, no staging) — the exchange step of the path.  A single
+// own PCIe link, or into a canvas on the first device with peer copies (one strided 2-D copy per chunk
+// and canvas over the peer's own xGMI link to the root: no ring, no staging; peer access is switched on
+// once in rtx_multi_create where the hardware allows it) — the exchange step of the path.  A single
 // process needs no collective library for peer-to-root copies; RCCL carries the same exchange where
 // ranks are processes (bench.py, ray-tracer_amd/tiling.py).
 //
@@ -42,6 +43,18 @@ int fail(int code, const std::string& msg) {
     return code;
 }
 
+// Restores the calling thread's current device when it goes out of scope: the entry points below move it around
+// (hipSetDevice per GPU), and a caller — torch, say — must find the device it had selected.
+struct DeviceGuard {
+    int saved = -1;
+    DeviceGuard() {
+        if (hipGetDevice(&saved) != hipSuccess) saved = -1;
+    }
+    ~DeviceGuard() {
+        if (saved >= 0) (void)hipSetDevice(saved);
+    }
+};
+
 struct Gpu {
     int device = 0;
     rtx_scene* scene = nullptr;
@@ -55,6 +68,7 @@ struct Gpu {
 
 struct rtx_multi {
     std::vector<Gpu> gpus;
+    uint32_t peer_links = 0;  // directed peer-access links to / from the first device that are switched on
 };
 
 namespace {
@@ -122,9 +136,7 @@ void add_stats(rtx_stats& a, const rtx_stats& b) {
 // One GPU's host thread: take chunks until none is left.
 void worker(Job* job, size_t gi, Result* res) {
     Gpu& g = job->m->gpus[gi];
-    const int root_device = job->m->gpus[0].device;
     const uint32_t W = job->cam->horizontal_size;
-    const uint32_t total = rendered_rows(job->cam, &job->opts);
     auto bail = [&](int rc, const std::string& what) {
         res->rc = rc;
         res->error = what;
@@ -150,23 +162,31 @@ void worker(Job* job, size_t gi, Result* res) {
         rc = rtx_render_device(g.scene, job->cam, &o, g.d_rgb, job->rgb8_out ? g.d_rgb8 : nullptr, g.stream, job->want_stats ? &st : nullptr);
         if (rc) return bail(rc, rtx_last_error());
         if (job->want_stats) add_stats(res->stats, st);
-        // The chunk's strips back to their rows: local strip j is global strip k + j * n_chunks.
-        uint32_t local = 0;
-        for (uint64_t s = k; s * kStripRows < total; s += job->n_chunks) {
-            const uint32_t y0 = (uint32_t)(s * kStripRows);
-            const uint32_t n = (total - y0 < kStripRows) ? total - y0 : kStripRows;
-            const size_t src = (size_t)local * W * 3, dst = (size_t)y0 * W * 3, count = (size_t)n * W * 3;
-            if (job->rgb_out) {
-                e = job->to_device ? hipMemcpyPeerAsync(job->rgb_out + dst, root_device, g.d_rgb + src, g.device, count * sizeof(float), g.stream)
-                                   : hipMemcpyAsync(job->rgb_out + dst, g.d_rgb + src, count * sizeof(float), hipMemcpyDeviceToHost, g.stream);
-                if (e != hipSuccess) return bail(RTX_E_HIP, std::string("canvas copy: ") + hipGetErrorString(e));
-            }
-            if (job->rgb8_out) {
-                e = job->to_device ? hipMemcpyPeerAsync(job->rgb8_out + dst, root_device, g.d_rgb8 + src, g.device, count, g.stream)
-                                   : hipMemcpyAsync(job->rgb8_out + dst, g.d_rgb8 + src, count, hipMemcpyDeviceToHost, g.stream);
-                if (e != hipSuccess) return bail(RTX_E_HIP, std::string("canvas copy: ") + hipGetErrorString(e));
-            }
-            local += n;
+        // The chunk's strips back to their rows: local strip j is global strip k + j * n_chunks, so the chunk is one
+        // 2-D copy per canvas — "rows" of one strip (16 * W * 3 elements) each, packed at the source and
+        // n_chunks strips apart at the destination — plus one short copy when the frame's last strip is partial
+        // and belongs to this chunk.
+        const size_t strip_elems = (size_t)kStripRows * W * 3;
+        const uint32_t full_strips = rows / kStripRows, tail_rows = rows % kStripRows;
+        auto put = [&](void* dst_base, const void* src_base, size_t elt) -> hipError_t {
+            char* dst = static_cast<char*>(dst_base) + (size_t)k * strip_elems * elt;
+            const char* src = static_cast<const char*>(src_base);
+            const hipMemcpyKind kind = job->to_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+            hipError_t err = hipSuccess;
+            if (full_strips)
+                err = hipMemcpy2DAsync(dst, (size_t)job->n_chunks * strip_elems * elt, src, strip_elems * elt, strip_elems * elt, full_strips, kind, g.stream);
+            if (err == hipSuccess && tail_rows)
+                err = hipMemcpyAsync(dst + (size_t)full_strips * job->n_chunks * strip_elems * elt, src + (size_t)full_strips * strip_elems * elt,
+                                     (size_t)tail_rows * W * 3 * elt, kind, g.stream);
+            return err;
+        };
+        if (job->rgb_out) {
+            e = put(job->rgb_out, g.d_rgb, sizeof(float));
+            if (e != hipSuccess) return bail(RTX_E_HIP, std::string("canvas copy: ") + hipGetErrorString(e));
+        }
+        if (job->rgb8_out) {
+            e = put(job->rgb8_out, g.d_rgb8, 1);
+            if (e != hipSuccess) return bail(RTX_E_HIP, std::string("canvas copy: ") + hipGetErrorString(e));
         }
         // The chunk buffers are reused by this GPU's next chunk: same stream, so the copies above
         // are ordered before the next render.
@@ -180,6 +200,7 @@ int multi_render(rtx_multi* m, const rtx_camera* cam, const rtx_opts* opts, uint
                  bool to_device, rtx_stats* stats) {
     if (!m || m->gpus.empty()) return fail(RTX_E_INVALID, "multi-GPU scene is NULL");
     if (!cam) return fail(RTX_E_INVALID, "camera is NULL");
+    DeviceGuard guard;  // worker 0 runs on this thread and selects its GPU
     if (!rgb_out && !rgb8_out) return fail(RTX_E_INVALID, "no output canvas");
     if (opts && (opts->strip_count > 1 || opts->compact_rows)) return fail(RTX_E_INVALID, "strips are this call's to set: leave strip_count and compact_rows zero");
     uint32_t probe = 0;
@@ -245,6 +266,7 @@ int rtx_multi_create(const rtx_scene_desc* desc, const int* devices, uint32_t n_
         devs.assign(devices, devices + n_devices);
     }
     if (devs.size() > 64) return fail(RTX_E_INVALID, "at most 64 devices");
+    DeviceGuard guard;
     rtx_multi* m = new (std::nothrow) rtx_multi();
     if (!m) return fail(RTX_E_NOMEM, "out of host memory");
     m->gpus.resize(devs.size());
@@ -264,12 +286,34 @@ int rtx_multi_create(const rtx_scene_desc* desc, const int* devices, uint32_t n_
             return fail(rc, msg);
         }
     }
+    // Peers write into canvases on the first device (rtx_multi_render_device): switch peer access on once, in both
+    // directions, where the hardware allows it (without it the runtime stages the copies through the host).
+    // "Already enabled" is not an error — another rtx_multi, or the caller, may have done it.
+    const int root = m->gpus[0].device;
+    for (size_t i = 1; i < m->gpus.size(); ++i) {
+        const int peer = m->gpus[i].device;
+        if (peer == root) continue;
+        for (int dir = 0; dir < 2; ++dir) {
+            const int from = dir ? root : peer, to = dir ? peer : root;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, from, to) != hipSuccess || !can) continue;
+            if (hipSetDevice(from) != hipSuccess) continue;
+            const hipError_t e = hipDeviceEnablePeerAccess(to, 0);
+            if (e == hipSuccess) m->peer_links++;
+            else if (e == hipErrorPeerAccessAlreadyEnabled) {
+                (void)hipGetLastError();
+                m->peer_links++;
+            }
+        }
+    }
+    (void)hipGetLastError();
     *out = m;
     return RTX_OK;
 }
 
 void rtx_multi_destroy(rtx_multi* m) {
     if (!m) return;
+    DeviceGuard guard;
     for (Gpu& g : m->gpus) {
         if (!g.scene && !g.stream && !g.d_rgb && !g.d_rgb8) continue;  // never set up (rtx_multi_create failed before it)
         (void)hipSetDevice(g.device);
@@ -285,6 +329,7 @@ void rtx_multi_destroy(rtx_multi* m) {
 }
 
 uint32_t rtx_multi_device_count(const rtx_multi* m) { return m ? (uint32_t)m->gpus.size() : 0u; }
+uint32_t rtx_multi_peer_links(const rtx_multi* m) { return m ? m->peer_links : 0u; }
 
 int rtx_multi_render(rtx_multi* m, const rtx_camera* cam, const rtx_opts* opts, uint32_t chunks_per_gpu, float* rgb_out,
                      uint8_t* rgb8_out, rtx_stats* stats) {

@@ -550,7 +550,9 @@ int rt_render(const rt_camera* cam, const rt_world* world, float* canvas, rt_ray
         rc = rtx_multi_create(rt_flat_desc(flat), devices.data(), (uint32_t)devices.size(), &multi);
         rt_flat_free(flat);
         if (rc) return rc;
-        rc = rtx_multi_render(multi, &rc_cam, &opts, 1, canvas, nullptr, &stats);
+        // two sets of strips per GPU: a GPU that finishes its first set early takes another (dynamic stealing,
+        // where the reference's bands are static, src/camera.zig:88,99)
+        rc = rtx_multi_render(multi, &rc_cam, &opts, 2, canvas, nullptr, &stats);
         rtx_multi_destroy(multi);
     } else {
         rtx_scene* scene = nullptr;
