@@ -58,7 +58,11 @@ typedef struct rtx_shape {
     uint32_t type;        /* RTX_* */
     uint32_t material;    /* index into rtx_scene_desc.materials */
     uint32_t flags;       /* RTX_SHAPE_* */
-    uint32_t reserved;
+    uint32_t reserved;    /* twin class: 0, or k >= 1 for a shape that has byte-identical twins (std.meta.eql) behind OTHER
+                             group boxes than its own — all members of one class carry the same k.  Which twins a ray
+                             intersects then depends on the boxes it passes, and the cancelling of equal Intersections
+                             (src/intersection.zig:126-137) is resolved per ray on the device.  At most 32 such shapes
+                             per scene.  Twins behind the same boxes are settled by RTX_SHAPE_N1_INVISIBLE instead */
     float    minimum;     /* cylinder / cone */
     float    maximum;
     float    pad[2];

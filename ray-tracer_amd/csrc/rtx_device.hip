@@ -25,6 +25,7 @@
 // Reference citations are file:line into /root/reference.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -154,6 +155,18 @@ constexpr uint32_t kHitIdentity = 1u << 23;     // the shape's inverse is exactl
 constexpr uint32_t kHitDiagonal = 1u << 24;     // ... is diag(a, b, c) plus a translation
 constexpr uint32_t kHitWorldNormal = 1u << 25;  // `n` is the hit's normal whatever the point
 static_assert(sizeof(HitRec) == 16, "one 16-byte load per hit");
+
+// Twin shapes behind different group boxes (rtx_shape.reserved != 0), resolved per ray by the TWINS kernels
+// (rtx_trace.inc: ClosestVisitor, resolve_twins).  Every such shape owns one bit of a 32-bit per-ray mask
+// ("slot"); the members of a class hold consecutive slots in insertion order.
+constexpr uint32_t kMaxTwinShapes = 32;
+struct TwinTable {
+    uint32_t n_classes;
+    uint32_t pad[3];
+    uint32_t member_shape[kMaxTwinShapes];  // slot -> shape index
+    uint32_t cls_first[kMaxTwinShapes];     // class -> its first slot
+    uint32_t cls_n[kMaxTwinShapes];         // class -> number of members
+};
 
 struct Totals {
     unsigned long long level_rays[kLevels];
@@ -391,6 +404,8 @@ struct rtx_scene {
     std::vector<DeviceTree> device_trees;
     std::vector<rtx_node> h_nodes;  // the gates as uploaded (BVH links included): refit re-uploads them with new boxes
     bool host_trees = false;        // some tree came from the host builder (such a scene cannot be refitted)
+    TwinTable h_twins{};            // twin shapes resolved per ray (n_classes == 0: none)
+    TwinTable* d_twins = nullptr;
     bool broken = false;            // a refit failed after it had started to overwrite device records: every render call fails
     rtx_material* d_materials = nullptr;
     rtx_pattern* d_patterns = nullptr;
@@ -614,6 +629,11 @@ template <bool GEN>
 TraceKernel book_kernel(bool bvh) {
     return bvh ? k_trace_shade<kTabGlobal, GEN, true, false, true, false, true> : k_trace_shade<kTabGlobal, GEN, true, false, false, false, true>;
 }
+// The same for scenes with twin shapes behind different group boxes (TWINS): the plainest form, correctness over speed.
+template <bool GEN>
+TraceKernel twin_kernel(bool bvh) {
+    return bvh ? k_trace_shade<kTabGlobal, GEN, true, false, true, false, false, true> : k_trace_shade<kTabGlobal, GEN, true, false, false, false, false, true>;
+}
 template <bool GEN>
 TraceKernel trace_kernel(bool track, uint32_t tab, bool canon, bool bvh, bool stats = false) {
     if (tab == (uint32_t)kTabAll) return pick_kernel<kTabAll, GEN>(track, canon, bvh, stats);
@@ -628,7 +648,9 @@ void launch_trace(const rtx_scene* s, const f32::Params& p, uint32_t level, uint
     // provided the reflectance is finite (0 * R must be 0): s->finite_schlick.  The last level
     // holds the most rays and runs the kernel without predecessor tracking.
     const bool track = s->track_n1 && !(level == p.depth && s->finite_schlick);
-    const TraceKernel k = (p.book && track) ? book_kernel<GEN>(p.has_bvh != 0) : trace_kernel<GEN>(track, p.tab_mode, p.canon != 0, p.has_bvh != 0, stats);
+    const TraceKernel k = (p.book && track) ? book_kernel<GEN>(p.has_bvh != 0)
+                          : (p.twins && track) ? twin_kernel<GEN>(p.has_bvh != 0)
+                                               : trace_kernel<GEN>(track, p.tab_mode, p.canon != 0, p.has_bvh != 0, stats);
     hipLaunchKernelGGL(k, dim3(blocks), dim3(256), p.lds_bytes, st, p, level);
 }
 
@@ -725,13 +747,14 @@ struct BvhInfo {
 // `linear` receives the gates without BVH links (rtx_opts.no_bvh).
 // `on_device` (may be NULL): classes whose tree the caller builds on the device (rtx_lbvh) instead —
 // listed with their hittable triangles, linked later (BvhInfo::root is meaningless until then).
-void prepare_shapes(std::vector<rtx_shape>& shapes);
-void build_bvhs(std::vector<rtx_shape>& shapes, std::vector<rtx_node>& nodes, std::vector<rtx_node>& linear,
-                std::vector<rtx_bvh::Node>& bvh_nodes, std::vector<rtx_bvh::Tri>& bvh_tris, std::vector<BvhInfo>* info = nullptr,
-                std::vector<BvhInfo>* on_device = nullptr);
+int prepare_shapes(std::vector<rtx_shape>& shapes, TwinTable* twins = nullptr);
+int build_bvhs(std::vector<rtx_shape>& shapes, std::vector<rtx_node>& nodes, std::vector<rtx_node>& linear,
+               std::vector<rtx_bvh::Node>& bvh_nodes, std::vector<rtx_bvh::Tri>& bvh_tris, std::vector<BvhInfo>* info = nullptr,
+               std::vector<BvhInfo>* on_device = nullptr, TwinTable* twins = nullptr);
 
-// Identity / diagonal flags and the finished world normals of planes and triangles.
-void prepare_shapes(std::vector<rtx_shape>& shapes) {
+// Identity / diagonal flags, the finished world normals of planes and triangles, and the slots of twin shapes
+// that are resolved per ray (rtx_shape.reserved; `twins`, if given, receives their table).
+int prepare_shapes(std::vector<rtx_shape>& shapes, TwinTable* twins) {
     static const float kIdentity[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     for (rtx_shape& sh : shapes) {
         bool ident = true;
@@ -749,12 +772,42 @@ void prepare_shapes(std::vector<rtx_shape>& shapes) {
             sh.flags |= kShapeWorldNormal;
         }
     }
+    // Twin classes (rtx_shape.reserved = k >= 1): members in insertion order get consecutive mask bits.
+    TwinTable table{};
+    std::vector<uint32_t> class_ids;
+    for (const rtx_shape& sh : shapes)
+        if (sh.reserved && std::find(class_ids.begin(), class_ids.end(), sh.reserved) == class_ids.end()) class_ids.push_back(sh.reserved);
+    uint32_t slot = 0;
+    for (uint32_t id : class_ids) {
+        std::vector<uint32_t> members;
+        for (uint32_t i = 0; i < shapes.size(); ++i)
+            if (shapes[i].reserved == id) members.push_back(i);
+        if (members.size() < 2) continue;  // a class of one has nothing to cancel against: an ordinary shape
+        if (slot + members.size() > kMaxTwinShapes || table.n_classes >= kMaxTwinShapes)
+            return fail(RTX_E_INVALID, "more than %u twin shapes behind different group boxes (rtx_shape.reserved)", kMaxTwinShapes);
+        table.cls_first[table.n_classes] = slot;
+        table.cls_n[table.n_classes] = (uint32_t)members.size();
+        ++table.n_classes;
+        for (size_t k = 0; k < members.size(); ++k, ++slot) {
+            rtx_shape& sh = shapes[members[k]];
+            if (sh.type != shapes[members[0]].type || sh.material != shapes[members[0]].material ||
+                std::memcmp(sh.inverse, shapes[members[0]].inverse, sizeof sh.inverse) != 0)
+                return fail(RTX_E_INVALID, "twin class %u: shapes %u and %u are not identical", id, members[0], members[k]);
+            table.member_shape[slot] = members[k];
+            sh.flags |= kShapeTwin | (slot << kShapeTwinSlotShift);
+            const bool survivor = (members.size() & 1u) && k + 1 == members.size();  // the rule when every member is reached
+            if (!survivor) sh.flags |= kShapeTwinStaticInvisible;
+        }
+    }
+    if (twins) *twins = table;
+    return RTX_OK;
 }
 
-void build_bvhs(std::vector<rtx_shape>& shapes, std::vector<rtx_node>& nodes, std::vector<rtx_node>& linear,
-                std::vector<rtx_bvh::Node>& bvh_nodes, std::vector<rtx_bvh::Tri>& bvh_tris, std::vector<BvhInfo>* info,
-                std::vector<BvhInfo>* on_device) {
-    prepare_shapes(shapes);
+int build_bvhs(std::vector<rtx_shape>& shapes, std::vector<rtx_node>& nodes, std::vector<rtx_node>& linear,
+               std::vector<rtx_bvh::Node>& bvh_nodes, std::vector<rtx_bvh::Tri>& bvh_tris, std::vector<BvhInfo>* info,
+               std::vector<BvhInfo>* on_device, TwinTable* twins) {
+    const int prc = prepare_shapes(shapes, twins);
+    if (prc) return prc;
     for (rtx_node& n : nodes) {
         n.reserved[0] = 0;
         n.reserved[1] = n.n_shapes;
@@ -777,7 +830,8 @@ void build_bvhs(std::vector<rtx_shape>& shapes, std::vector<rtx_node>& nodes, st
         for (uint32_t i = c; i < nn; ++i) {
             if (cls[i] != c) continue;
             uint32_t lin = nodes[i].n_shapes;
-            while (lin > 0 && shapes[nodes[i].first_shape + lin - 1].type == RTX_TRIANGLE) --lin;
+            // (a twin triangle that is resolved per ray stays on the linear path, where the walk sees it)
+            while (lin > 0 && shapes[nodes[i].first_shape + lin - 1].type == RTX_TRIANGLE && !(shapes[nodes[i].first_shape + lin - 1].flags & kShapeTwin)) --lin;
             members.push_back(i);
             n_lin.push_back(lin);
             for (uint32_t k = lin; k < nodes[i].n_shapes; ++k) tris.push_back(nodes[i].first_shape + k);
@@ -801,6 +855,7 @@ void build_bvhs(std::vector<rtx_shape>& shapes, std::vector<rtx_node>& nodes, st
         nodes[members.back()].reserved[0] = root + 1;
         if (info) info->push_back(BvhInfo{root, members.back(), tris, {}});
     }
+    return RTX_OK;
 }
 
 // The gates as the kernels walk them: a node that has nothing to test — no box of its own, no linearly tested
@@ -864,6 +919,7 @@ void fill_scene_params(const rtx_scene* s, P& p, uint32_t depth) {
     p.nodes = s->d_nodes;
     p.bvh_nodes = s->d_bvh_nodes;
     p.bvh_tris = s->d_bvh_tris;
+    p.twins = s->d_twins;
     p.has_bvh = s->n_bvh_nodes ? 1u : 0u;
     p.finite_schlick = s->finite_schlick ? 1u : 0u;
     p.shadow_skip = s->shadow_skip ? 1u : 0u;  // render_impl_t clears it for rtx_opts.all_shadows
@@ -1088,6 +1144,12 @@ int render_impl_t(rtx_scene* s, const rtx_camera* cam, const rtx_opts* opts, flo
     if (opts && opts->containers == RTX_CONTAINERS_BOOK && s->track_n1) {
         // every level of the frame runs the plain variants (see book_kernel): one ray format, no LDS tables
         p.book = 1u;
+        p.canon = 0u;
+        p.tab_mode = (uint32_t)kTabGlobal;
+        p.lds_bytes = 0u;
+    }
+    if (p.twins && !p.book && s->track_n1) {
+        // twin shapes behind different group boxes: every level runs the plain variants (see twin_kernel)
         p.canon = 0u;
         p.tab_mode = (uint32_t)kTabGlobal;
         p.lds_bytes = 0u;
@@ -1345,7 +1407,9 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out) {
         t_last = now;
     };
     std::vector<BvhInfo> deferred;
-    build_bvhs(shapes, nodes, linear, bvh_nodes, bvh_tris, nullptr, device_build ? &deferred : nullptr);
+    rc = build_bvhs(shapes, nodes, linear, bvh_nodes, bvh_tris, nullptr, device_build ? &deferred : nullptr, &s->h_twins);
+    if (rc) return bail(rc);
+    if (s->h_twins.n_classes) HIP_TRY_S(upload((void**)&s->d_twins, &s->h_twins, sizeof(TwinTable)));
     s->host_trees = !bvh_nodes.empty();
     lap(device_build ? "shape records + classes" : "shape records + host trees");
     HIP_TRY_S(upload((void**)&s->d_shapes, shapes.data(), sizeof(rtx_shape) * shapes.size()));
@@ -1438,6 +1502,7 @@ void rtx_scene_destroy(rtx_scene* s) {
     if (s->d_canvas) (void)hipFree(s->d_canvas);
     if (s->d_shapes) (void)hipFree(s->d_shapes);
     if (s->d_hitrecs) (void)hipFree(s->d_hitrecs);
+    if (s->d_twins) (void)hipFree(s->d_twins);
     if (s->d_nodes) (void)hipFree(s->d_nodes);
     if (s->d_nodes_linear) (void)hipFree(s->d_nodes_linear);
     for (rtx_scene::DeviceTree& t : s->device_trees) rtx_lbvh::destroy(t.tree);
@@ -1471,7 +1536,13 @@ int rtx_scene_refit(rtx_scene* s, const rtx_scene_desc* desc) {
     // nothing orders them against the copies below): wait for all of them before a record changes.
     HIP_TRY(hipDeviceSynchronize());
     std::vector<rtx_shape> shapes(desc->shapes, desc->shapes + desc->n_shapes);
-    prepare_shapes(shapes);
+    {
+        TwinTable twins{};
+        rc = prepare_shapes(shapes, &twins);
+        if (rc) return rc;
+        if (std::memcmp(&twins, &s->h_twins, sizeof twins) != 0)
+            return fail(RTX_E_INVALID, "rtx_scene_refit: the twin classes (rtx_shape.reserved) changed");
+    }
     {   // what a tree holds may move, not change kind: a triangle stays a (hittable) triangle.  Material indices stay
         // too: track_n1 / can_spawn / two_children / finite_schlick — and with them the sizes of the ray queues and
         // the ray-tree node regions — were fixed at creation from the materials the shapes referenced then.
@@ -1624,7 +1695,8 @@ int rtx_bvh_selftest(const rtx_scene_desc* desc, const float* origins, const flo
     std::vector<rtx_bvh::Node> bn;
     std::vector<rtx_bvh::Tri> bt;
     std::vector<BvhInfo> trees;
-    build_bvhs(shapes, nodes, linear, bn, bt, &trees);
+    rc = build_bvhs(shapes, nodes, linear, bn, bt, &trees);
+    if (rc) return rc;
     g_selftest_nodes = g_selftest_tris = 0;
     if (n_bvh_nodes) *n_bvh_nodes = (uint32_t)bn.size();
     if (n_bvh_tris) *n_bvh_tris = (uint32_t)bt.size();
@@ -1734,6 +1806,8 @@ int rtx_color_at(rtx_scene* s, const float* origins, const float* directions, ui
     // Canonical kernels need canonical rays too: origins with w == 1, directions with w == 0.
     bool canon = s->canon;
     for (uint32_t i = 0; i < n && canon; ++i) canon = origins[4 * i + 3] == 1.0f && directions[4 * i + 3] == 0.0f;
+    const bool twins = s->d_twins && s->track_n1;  // the plain variants, as in render_impl_t
+    if (twins) canon = false;
     WorkSet& w = s->ws[0];
     int rc = ensure_work(s, &w, n, !canon);
     if (rc) return rc;
@@ -1761,6 +1835,10 @@ int rtx_color_at(rtx_scene* s, const float* origins, const float* directions, ui
     Params p;
     fill_scene_params(s, p, depth);
     p.canon = canon ? 1u : 0u;
+    if (twins) {
+        p.tab_mode = (uint32_t)kTabGlobal;
+        p.lds_bytes = 0u;
+    }
     p.canvas = s->d_canvas;
     p.root_count = n;
     rc = run_levels<false>(s, w, p, n, n, st, false, true, false);

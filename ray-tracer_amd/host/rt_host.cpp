@@ -358,20 +358,36 @@ struct Flattener {
         // The world node has no box: a ray never skips it, and its own "subtree" is just itself.
         out.nodes[0].skip = 1;
 
-        // Limit of the static flag: the reference cancels two equal shapes only for rays that intersect
-        // both, i.e. that pass both shapes' group boxes.  Equal shapes sit in the same place, so their
-        // boxes — whatever groups they belong to — are passed or failed together by nearly every ray
-        // and the flag is exact there; a ray that passes one box and not the other (boxes of different
-        // extent around the twins) sees the surviving twin as a predecessor in the reference and not
-        // here.  Keying the flag on the gate chain instead would turn the common case wrong.
-        // Shapes equal under std.meta.eql produce equal Intersections that toggle each other out
-        // of the n1/n2 container walk (src/intersection.zig:126-137): with m equal shapes only the
-        // last one survives, and only when m is odd.
+        // Shapes equal under std.meta.eql produce equal Intersections that toggle each other out of the n1/n2
+        // container walk (src/intersection.zig:126-137): of m equal shapes a ray intersects, only the last
+        // survives, and only when m is odd.  Which of them a ray intersects depends on the group boxes it passes
+        // (src/group.zig:58).  Twins behind the SAME chain of boxes are intersected together or not at all, so the
+        // outcome is the same for every ray and is recorded here (RTX_SHAPE_N1_INVISIBLE).  Twins behind DIFFERENT
+        // chains are resolved per ray on the device: they carry their class number in rtx_shape.reserved.
+        std::vector<uint32_t> node_of(out.shapes.size(), 0u);
+        for (uint32_t n = 0; n < out.nodes.size(); ++n)
+            for (uint32_t k = 0; k < out.nodes[n].n_shapes; ++k) node_of[out.nodes[n].first_shape + k] = n;
+        auto gate_chain = [&](uint32_t shape) {  // the boxed nodes a ray must pass to reach the shape, outermost first
+            std::vector<uint32_t> chain;
+            const uint32_t at = node_of[shape];
+            for (uint32_t n = 1; n <= at; ++n)
+                if (out.nodes[n].skip > at && out.nodes[n].has_bounds) chain.push_back(n);
+            return chain;
+        };
         std::map<std::string, std::vector<uint32_t>> classes;
         for (uint32_t i = 0; i < out.eq_keys.size(); ++i) classes[out.eq_keys[i]].push_back(i);
+        uint32_t split_classes = 0;
         for (auto& kv : classes) {
             const std::vector<uint32_t>& ids = kv.second;
             if (ids.size() < 2) continue;
+            bool same_chain = true;
+            const std::vector<uint32_t> first_chain = gate_chain(ids[0]);
+            for (size_t k = 1; k < ids.size() && same_chain; ++k) same_chain = gate_chain(ids[k]) == first_chain;
+            if (!same_chain) {
+                ++split_classes;
+                for (uint32_t id : ids) out.shapes[id].reserved = split_classes;
+                continue;
+            }
             for (size_t k = 0; k < ids.size(); ++k) {
                 const bool survivor = (ids.size() & 1) && k + 1 == ids.size();
                 if (!survivor) out.shapes[ids[k]].flags |= RTX_SHAPE_N1_INVISIBLE;

@@ -156,6 +156,70 @@ def test_duplicate_intersections_cancel_in_the_n1_walk():
     scene2.close()
 
 
+def _twin_world(n_twins=2):
+    """Byte-identical dense glass spheres, each in a group of its own whose box the test sets by hand: the first box is
+    a thin column inside the sphere, the others hold it whole — so some rays reach every twin and others all but the
+    first.  The reference cancels equal Intersections per ray (src/intersection.zig:126-137, src/group.zig:58)."""
+    glass = st.default_attrs()
+    glass.material.transparency = 0.9
+    glass.material.reflective = 0.5
+    glass.material.refractive_index = 1.5
+    front = st.Sphere(glass)
+    front.common_attrs.transform = su.translation(0, 0, 5)
+    dense = st.default_attrs()
+    dense.material.refractive_index = 2.4
+    dense.material.transparency = 0.5
+    dense.material.color[:] = [0.3, 0.5, 0.9]
+    twin = st.Sphere(dense)
+    twin.common_attrs.transform = su.translation(0, 0, -5)
+    behind = st.default_attrs()
+    behind.material.refractive_index = 1.2
+    behind.material.transparency = 0.5
+    wall = st.Plane(behind)
+    wall.common_attrs.transform = su.compose(su.translation(0, 0, -8), su.rotation("x", float(np.float32(np.pi / 2))))
+    floor = st.Plane(st.default_attrs())
+    floor.common_attrs.transform = su.translation(0, -3, 0)
+    floor.common_attrs.material.has_pattern = 1
+    floor.common_attrs.material.pattern.a[:] = [1, 0, 0]
+    floor.common_attrs.material.pattern.b[:] = [0, 1, 0]
+    floor.common_attrs.material.pattern.color_map = st.PATTERN_CHECKER
+    keep = []
+    groups = []
+    for k in range(n_twins):
+        b = st.Bounds()
+        half = 0.3 if k == 0 else 1.0 + 0.25 * k
+        b.minimum[:] = [-half, -half, -6.5, 1]
+        b.maximum[:] = [half, half, -3.5, 1]
+        groups.append(st.make_group(bounding_box=b, keep=keep, spheres=[twin]))
+    w, keep = st.make_world([2, 6, -3, 1], [1, 1, 1], groups=groups, keep=keep, spheres=[front], planes=[wall, floor])
+    return w, keep
+
+
+@pytest.mark.parametrize("n_twins", [2, 3])
+def test_twins_behind_different_boxes_cancel_per_ray(n_twins):
+    w, keep = _twin_world(n_twins)
+    flat = rta.FlatScene(w)
+    cls = [flat.desc.shapes[i].reserved for i in range(flat.desc.n_shapes)]
+    assert sorted(c for c in cls if c) == [1] * n_twins and not any(flat.desc.shapes[i].flags & 2 for i in range(flat.desc.n_shapes))
+    # rays along +z from z = 0: x = 0 passes every box, x = 0.5 misses the thin first one, x = 2.5 misses all
+    origins = np.array([[0, 0, 0, 1], [0.1, 0.05, 0, 1], [0.5, 0, 0, 1], [0.45, 0.2, 0, 1], [2.5, 0, 0, 1], [0.29, 0, 0, 1], [0.31, 0, 0, 1]], np.float32)
+    dirs = np.array([[0, 0, 1, 0]] * len(origins), np.float32)
+    scene = rta.Scene(w)
+    gpu = scene.color_at(origins, dirs)
+    ref = np.stack([o.color_at(w, origins[i], dirs[i]) for i in range(len(origins))])
+    compare(gpu[None], ref[None], "twins behind different boxes (%d)" % n_twins)
+    assert not np.array_equal(ref[0], ref[2])  # the two kinds of ray do see different predecessors
+    # a camera behind the twins looks through them: rays refracted inside pass one box or several
+    cam = su.default_camera(96, 96, 0.6, frm=(0.2, 0.1, -9, 1), to=(0, 0, -5, 1))
+    g, sg = scene.render(cam)
+    r, counts = o.render(cam, w)
+    compare(g, r, "twins behind different boxes (%d), rendered" % n_twins)
+    assert sg.rays_total == counts.total
+    g2, _ = scene.render(cam, no_bvh=True, batch_pixels=2048)
+    assert g2.tobytes() == g.tobytes()
+    scene.close()
+
+
 def test_rows_quirk_leaves_remainder_rows_black():
     s = rta.Sample("sphere_world", 100, 70)  # 8*floor(70/8) = 64 rows rendered (camera.zig:87-88)
     scene = rta.Scene(s.world)
@@ -205,6 +269,19 @@ def test_full_size_is_independent_of_batching_and_strips():
     ref, _ = o.render(s.camera, s.world, row_step=135)
     ys = [y for y in range(1080) if (y % 135) == 0]
     compare(a[ys], ref[ys], "1920x1080 sampled rows")
+    scene.close()
+
+
+def test_fresnel_full_size_sampled_rows_match_oracle():
+    """The other half of BASELINE configs[1]: fresnel at 1920x1080, every 135th row against the oracle."""
+    s = rta.Sample("fresnel", 1920, 1080)
+    scene = rta.Scene(s.world)
+    a, sa = scene.render(s.camera)
+    b, sb = scene.render(s.camera, batch_pixels=1 << 17)
+    assert a.tobytes() == b.tobytes() and sa.rays_total == sb.rays_total
+    ref, _ = o.render(s.camera, s.world, row_step=135)
+    ys = [y for y in range(1080) if (y % 135) == 0]
+    compare(a[ys], ref[ys], "fresnel 1920x1080 sampled rows")
     scene.close()
 
 
@@ -998,6 +1075,19 @@ def test_f64_instantiation_on_a_mesh_with_bvh():
     assert a.tobytes() == b.tobytes() and sa.rays_total == sb.rays_total == sc.rays_total
     d = np.abs(rta.to_ppm_bytes(a).astype(np.int32) - rta.to_ppm_bytes(c).astype(np.int32)).max(axis=-1)
     assert (d <= 1).mean() >= 0.999
-    with pytest.raises(rta.RtxError):
-        scene.render(cam, f64=True, book=True) if sa.kernel_flags & rta.RtxStats.KERNEL_TRACK_N1 else (_ for _ in ()).throw(rta.RtxError(-1, "no transparency"))
+    scene.close()
+
+
+def test_f64_with_the_book_walk_is_rejected():
+    """The f64 reporting mode renders with the reference's own container walk only: on a scene that tracks n1
+    (glass) the combination is an error, not a silent fallback."""
+    s = rta.Sample("glass_spheres", 48, 48)
+    scene = rta.Scene(s.world)
+    _, st32 = scene.render(s.camera)
+    assert st32.kernel_flags & rta.RtxStats.KERNEL_TRACK_N1
+    with pytest.raises(rta.RtxError, match="container walk"):
+        scene.render(s.camera, f64=True, book=True)
+    a, _ = scene.render(s.camera, f64=True)  # each of them alone is fine
+    b, _ = scene.render(s.camera, book=True)
+    assert a.any() and b.any()
     scene.close()

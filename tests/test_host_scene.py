@@ -87,6 +87,33 @@ def test_flatten_marks_identical_shapes_invisible_to_n1():
     assert [d.shapes[i].flags & 2 for i in range(3)] == [2, 2, 0]  # three equal: only the last survives
 
 
+def test_flatten_sends_twins_behind_different_boxes_to_the_per_ray_rule():
+    """Equal shapes cancel only for rays that reach both (intersection.zig:126-137 after group.zig:58): twins behind the
+    same chain of boxes get the static flag, twins behind different chains carry a class number instead."""
+    a = st.Sphere(st.default_attrs())
+    keep = []
+    box = st.Bounds()
+    box.minimum[:] = [-1, -1, -1, 1]
+    box.maximum[:] = [1, 1, 1, 1]
+    small = st.Bounds()
+    small.minimum[:] = [-0.5, -0.5, -0.5, 1]
+    small.maximum[:] = [0.5, 0.5, 0.5, 1]
+    g_same = st.make_group(bounding_box=box, keep=keep, spheres=[a, a])           # same chain: static rule
+    w, keep = st.make_world([0, 5, -5, 1], [1, 1, 1], groups=[g_same], keep=keep)
+    d = rta.FlatScene(w).desc
+    assert [d.shapes[i].flags & 2 for i in range(2)] == [2, 2] and [d.shapes[i].reserved for i in range(2)] == [0, 0]
+    g1 = st.make_group(bounding_box=box, keep=keep, spheres=[a])
+    g2 = st.make_group(bounding_box=small, keep=keep, spheres=[a])
+    w, keep = st.make_world([0, 5, -5, 1], [1, 1, 1], groups=[g1, g2], keep=keep, spheres=[a])
+    d = rta.FlatScene(w).desc
+    assert [d.shapes[i].flags & 2 for i in range(3)] == [0, 0, 0] and [d.shapes[i].reserved for i in range(3)] == [1, 1, 1]
+    # an unbounded group adds no gate: its member shares the world-level twin's (empty) chain
+    g3 = st.make_group(keep=keep, spheres=[a])
+    w, keep = st.make_world([0, 5, -5, 1], [1, 1, 1], groups=[g3], keep=keep, spheres=[a])
+    d = rta.FlatScene(w).desc
+    assert [d.shapes[i].flags & 2 for i in range(2)] == [2, 2] and [d.shapes[i].reserved for i in range(2)] == [0, 0]
+
+
 def test_materials_and_patterns_are_deduplicated():
     s = rta.Sample("sphere_world")
     d = rta.FlatScene(s.world).desc
