@@ -95,8 +95,8 @@ def measured_traffic():
         with open(path) as f:
             d = json.load(f)
         if d.get("frame") == "composite %dx%d" % (WIDTH, HEIGHT):
-            return float(d["bytes_per_launch"]), os.path.relpath(path, ROOT)
-    return None, None
+            return float(d["bytes_per_launch"]), os.path.relpath(path, ROOT), d.get("library_build")
+    return None, None, None
 
 
 def measured_flops():
@@ -109,8 +109,8 @@ def measured_flops():
         with open(path) as f:
             d = json.load(f)
         if d.get("frame") == "composite %dx%d" % (WIDTH, HEIGHT):
-            return d["f32"], os.path.relpath(path, ROOT)
-    return None, None
+            return d["f32"], os.path.relpath(path, ROOT), d.get("library_build")
+    return None, None, None
 
 
 def usable_threads():
@@ -159,6 +159,61 @@ def self_launch(args):
     return subprocess.run(cmd, env=env).returncode
 
 
+def in_process(args):
+    """--gpus N --in-process: the same frame through rtx_multi_render_device — one process, one host thread per GPU, strip sets
+    handed out from a shared counter (stealing when chunks_per_gpu > 1), peers copying their strips into the canvas on
+    GPU 0 over their own xGMI link.  Each call blocks until the frame is complete, so a step is a whole frame, exchange
+    included.  With fewer visible GPUs than asked for, device 0 is listed N times: a rehearsal of the path, not a measurement."""
+    import torch
+
+    rta = importlib.import_module("ray-tracer_amd")
+    n = args.gpus
+    visible = torch.cuda.device_count()
+    rehearse = visible < n
+    devices = [0] * n if rehearse else list(range(n))
+    torch.cuda.set_device(0)
+    obj_text = rta.teapot_obj_text(1)
+    world, cam, keep = rta.composite_scene(obj_text, WIDTH, HEIGHT)
+    fcam = rta.flatten_camera(cam)
+    multi = rta.MultiScene(world, devices=devices)
+    rgb = torch.zeros((HEIGHT, WIDTH, 3), dtype=torch.float32, device="cuda:0")
+    rgb8 = torch.zeros((HEIGHT, WIDTH, 3), dtype=torch.uint8, device="cuda:0")
+    stats = multi.render_device(fcam, rgb.data_ptr(), rgb8.data_ptr(), chunks_per_gpu=args.chunks_per_gpu, want_stats=True)
+    for _ in range(args.warmup):
+        multi.render_device(fcam, rgb.data_ptr(), rgb8.data_ptr(), chunks_per_gpu=args.chunks_per_gpu)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        multi.render_device(fcam, rgb.data_ptr(), rgb8.data_ptr(), chunks_per_gpu=args.chunks_per_gpu)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if rehearse:  # the canvas the peers assembled must be the single-GPU canvas
+        single = rta.Scene(world, device=0)
+        want = rta.to_ppm_bytes(single.render(fcam)[0])
+        single.close()
+        assert (rgb8.cpu().numpy() == want).all(), "rtx_multi_render_device: canvas differs from the single-GPU render"
+    out = {
+        "metric": "Mrays/s (primary+shadow+secondary)", "value": stats.rays_total * args.steps / dt / 1e6, "unit": "Mrays/s",
+        "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": "composite (generated teapot.obj, 1568 triangles + glass_spheres' two spheres + reflective_floor's plane and sphere; "
+                        "camera/light of samples/teapot.zig) at %dx%d, depth 5, one step = one frame" % (WIDTH, HEIGHT),
+            "rays_per_step": int(stats.rays_total), "frame_ms": dt / args.steps * 1e3,
+            "parallelism": "one process, %d GPUs: rtx_multi_render_device, %d sets of 16-row strips per GPU taken from a shared counter "
+                           "(dynamic stealing), peer copies into the canvas on GPU 0 (peer links enabled: %d); every call blocks until "
+                           "the frame is complete" % (n, args.chunks_per_gpu, multi.peer_links),
+        },
+        "library_build": rta.build_id(),
+    }
+    if rehearse:
+        out["rehearsal"] = True
+        out["note"] = "device 0 listed %d times: a check of the in-process N > 1 path, not a measurement" % n
+    print(json.dumps(out), flush=True)
+    multi.close()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -171,10 +226,17 @@ def main():
                     help="only the timed frame loop: no D2H leg, no f64 report, no other configs, no CPU legs (what profiles/ traces: "
                          "every k_trace_shade launch of the run is then one of the headline frame, running alone)")
     ap.add_argument("--no-events", action="store_true", help="experiment: no per-launch HIP events in the timed loop")
+    ap.add_argument("--in-process", action="store_true",
+                    help="N > 1: one process drives all N GPUs through rtx_multi_render_device (one host thread per GPU, strip sets "
+                         "taken from a shared counter: the path with dynamic stealing; peer copies into a canvas on GPU 0) instead of "
+                         "one rank per GPU over RCCL")
+    ap.add_argument("--chunks-per-gpu", type=int, default=2, help="--in-process: strip sets per GPU (> 1: stealing)")
     ap.add_argument("--whole-frames", action="store_true",
                     help="N > 1: deal whole frames to the ranks (weak scaling) instead of splitting every frame into strips")
     args = ap.parse_args()
     n = args.gpus
+    if n > 1 and args.in_process:
+        sys.exit(in_process(args))
     if n > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
 
@@ -280,6 +342,41 @@ def main():
         print("rehearsal (%s): the canvases gathered from %d ranks equal the whole-frame render" % (
             "split frames" if split else "whole frames", n), file=sys.stderr, flush=True)
 
+    # What a scaling record needs next to the headline: every rank's own render time for its share (device time of the
+    # render calls alone, nothing else in flight) and what one canvas exchange costs when nothing hides it.  Untimed
+    # extras, after the measured loop.
+    scaling_detail = None
+    if n > 1:
+        reps = max(3, min(20, args.steps))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        fence()
+        e0.record(tstream)
+        for k in range(reps):
+            scene.render_device(fcam, rgb.data_ptr(), rgb8[k & 1].data_ptr(), stream=stream, strips=strips, compact_rows=split, lanes=args.lanes)
+        e1.record(tstream)
+        torch.cuda.synchronize()
+        render_ms = e0.elapsed_time(e1) / reps
+        fence()
+        t_x = time.perf_counter()
+        for k in range(reps):
+            if exchange is not None:
+                exchange.submit(0, rgb8[0])
+                exchange.finish(0)
+            else:
+                src = rgb8[0].cpu() if rehearse else rgb8[0]
+                dist.gather(src, whole_slots[0] if rank == 0 else None, dst=0)
+            torch.cuda.synchronize()
+        exchange_ms = (time.perf_counter() - t_x) / reps * 1e3
+        mine = torch.tensor([render_ms, exchange_ms, float(rays_local)], dtype=torch.float64, device=torch.device("cpu") if rehearse else dev)
+        everyone = [torch.zeros_like(mine) for _ in range(n)]
+        dist.all_gather(everyone, mine)
+        scaling_detail = {
+            "per_rank": [{"rank": r, "render_ms": float(v[0]), "exchange_ms_unhidden": float(v[1]), "rays": int(v[2])} for r, v in enumerate(everyone)],
+            "note": "render_ms: device time of a rank's own render calls with nothing else in flight; exchange_ms_unhidden: wall time of one "
+                    "canvas exchange (gather on rank 0 + re-interleave) with nothing to overlap it; in the measured loop the exchange of "
+                    "step k overlaps the rendering of step k + 1",
+        }
+
     t = torch.tensor([dt, float(rays_local)], dtype=torch.float64, device=torch.device("cpu") if rehearse or n == 1 else dev)
     if n > 1:
         tmax = t.clone()
@@ -361,8 +458,9 @@ def main():
         profiled_steps = len(range(EVENT_EVERY // 2, args.steps, EVENT_EVERY)) if not args.no_events else 0
         flops_per_launch = flops_frame * profiled_steps / max(launches, 1)
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-        traffic, traffic_src = measured_traffic() if n == 1 else (None, None)  # the PMC pass is of whole frames
-        hw_flops, hw_flops_src = measured_flops() if n == 1 else (None, None)
+        traffic, traffic_src, traffic_build = measured_traffic() if n == 1 else (None, None, None)  # the PMC pass is of whole frames
+        hw_flops, hw_flops_src, hw_flops_build = measured_flops() if n == 1 else (None, None, None)
+        build = rta.build_id()  # hash of the library's sources: counter files quoted here say which build they measured
         frames_per_step = 1 if n == 1 or split else n
         out = {
             "metric": "Mrays/s (primary+shadow+secondary)",
@@ -396,8 +494,10 @@ def main():
                 "frac": achieved / VALU_PEAK_FMA_TFLOPS,
                 "frac_of_unfused_issue_rate": achieved / VALU_PEAK_UNFUSED_TFLOPS, "frac_of_spec_peak": achieved / VALU_PEAK_SPEC_TFLOPS,
                 "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
+                "traffic_stale": (traffic_build != build) if traffic is not None else None,
                 "hw_flop_counters": ({"flop_slots_per_frame": hw_flops["flop_slots"], "flops_on_active_lanes_per_frame": hw_flops["flops_active_lanes"],
-                                      "lanes_active": hw_flops["lanes_active"], "source": hw_flops_src} if hw_flops else None),
+                                      "lanes_active": hw_flops["lanes_active"], "source": hw_flops_src,
+                                      "stale": hw_flops_build != build} if hw_flops else None),
                 "flops_per_launch": flops_per_launch, "flops_per_frame": flops_frame, "avg_launch_ms": avg_ms, "launches": launches,
                 "share_of_step": (prof.ms_trace_shade / profiled_steps) / (dt / args.steps * 1e3) if dt > 0 and profiled_steps else None,
                 "events": {"shape_tests": list(stats.shape_tests), "gate_tests": stats.gate_tests, "bvh_box_tests": stats.bvh_box_tests,
@@ -410,9 +510,13 @@ def main():
                         "FMA); flops = SURVEY 8d's table x the device's event counts (`events`, of this rank's share of one frame); "
                         "durations: rank 0's launches of every %d-th timed step, bracketed by HIP events on the render stream (those "
                         "frames run on one stream); traffic = HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE) from the committed "
-                        "PMC pass named in traffic_source" % EVENT_EVERY,
+                        "PMC pass named in traffic_source; *_stale: that file was measured on another build of the library than the one "
+                        "loaded now (library_build)" % EVENT_EVERY,
             },
+            "library_build": build,
         }
+        if scaling_detail is not None:
+            out["scaling_detail"] = scaling_detail
         if rehearse and n > 1:
             out["rehearsal"] = True
             out["note"] = "all %d ranks shared GPU 0 over gloo: a check of the N > 1 code path, not a measurement" % n
@@ -449,8 +553,13 @@ def other_configs(rta, torch, dev, stream, obj_text, frames=10):
             scene.render_device(fcam, rgb.data_ptr(), rgb8.data_ptr(), stream=stream)
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / frames * 1e3
+        flops = trace_shade_flops(st)
         rows.append({"config": config, "scene": label, "size": "%dx%d" % (w, h), "shapes": scene.n_shapes, "rays_per_frame": st.rays_total,
-                     "frame_ms": ms, "mrays_per_s": st.rays_total / ms / 1e3, "flops_per_frame": trace_shade_flops(st)})
+                     "frame_ms": ms, "mrays_per_s": st.rays_total / ms / 1e3, "flops_per_frame": flops,
+                     # the frame's algorithmic flops over the WHOLE frame time (level kernels + combine + quantise), so a lower
+                     # bound on the dominant kernel's own fraction
+                     "kernel": "k_trace_shade", "achieved_tflops_whole_frame": flops / (ms * 1e-3) / 1e12,
+                     "frac": flops / (ms * 1e-3) / 1e12 / VALU_PEAK_FMA_TFLOPS})
         scene.close()
         del rgb, rgb8
 

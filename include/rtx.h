@@ -355,6 +355,10 @@ void rtx_bvh_selftest_work(uint64_t* box_tests, uint64_t* triangle_tests);
 
 const char* rtx_last_error(void);
 
+/* A short hash of the sources this library was built from (ray-tracer_amd/Makefile): lets measurements kept in files
+ * say which build they were taken on. */
+const char* rtx_build_id(void);
+
 /* sizeof of the public structs as this library was compiled (0 rtx_shape, 1 rtx_material, 2 rtx_pattern, 3 rtx_node,
  * 4 rtx_scene_desc, 5 rtx_camera, 6 rtx_opts, 7 rtx_stats): lets a binding in another language check its mirrors. */
 uint32_t rtx_struct_size(uint32_t which);

@@ -112,6 +112,7 @@ _SIGNATURES = [
     ("rtx_bvh_selftest_work", None, [P(C.c_uint64), P(C.c_uint64)]),
     ("rtx_last_error", C.c_char_p, []),
     ("rtx_struct_size", u32, [u32]),
+    ("rtx_build_id", C.c_char_p, []),
     ("rt_camera_init", None, [u32, u32, f32, P(f32), P(f32), P(f32), P(st.Camera)]),
     ("rt_ray_for_pixel", None, [P(st.Camera), u32, u32, P(st.Ray)]),
     ("rt_render", C.c_int, [P(st.Camera), P(st.World), P(f32), P(st.RayCounts)]),
@@ -191,6 +192,11 @@ def lib():
         fn.argtypes = argtypes
     _lib = L
     return L
+
+
+def build_id():
+    """rtx_build_id(): hash of the sources the loaded library was built from."""
+    return lib().rtx_build_id().decode()
 
 
 def _check(rc):

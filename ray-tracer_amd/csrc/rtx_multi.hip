@@ -341,6 +341,11 @@ int rtx_multi_render_device(rtx_multi* m, const rtx_camera* cam, const rtx_opts*
     return multi_render(m, cam, opts, chunks_per_gpu, (float*)d_rgb_out, (uint8_t*)d_rgb8_out, true, stats);
 }
 
+#ifndef RTX_BUILD_ID
+#define RTX_BUILD_ID "unknown"
+#endif
+const char* rtx_build_id(void) { return RTX_BUILD_ID; }
+
 uint32_t rtx_struct_size(uint32_t which) {
     switch (which) {
     case 0: return (uint32_t)sizeof(rtx_shape);

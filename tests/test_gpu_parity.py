@@ -1029,6 +1029,59 @@ def test_refit_follows_a_moving_mesh():
     dev.close()
 
 
+def test_refit_rejects_what_it_cannot_honour_and_leaves_the_scene_whole():
+    """A refit may move shapes, not re-assign materials (the work buffers were sized for the materials in use at creation)
+    or make a triangle unboundable; either is refused before any device record changes."""
+    def world(glassy, singular):
+        obj = rta.ObjFile(_teapot_text(), bound=False)
+        if singular:
+            obj.group.transform = su.scaling(1.0, 0.0, 1.0)  # not invertible: its triangles cannot be bounded
+        ball = st.Sphere(st.default_attrs())
+        ball.common_attrs.transform = su.translation(4, 1, 0)
+        if glassy:
+            ball.common_attrs.material.transparency = 0.9
+            ball.common_attrs.material.reflective = 0.9
+            ball.common_attrs.material.refractive_index = 1.5
+        w, keep = st.make_world([-6, 9, -8, 1], [1, 1, 1], groups=[obj.group], spheres=[ball])
+        keep.append(obj)
+        return w, keep
+
+    cam = rta.camera(160, 120, 1.0, (0, 4, -11, 1), (0, 1.5, 0, 1), (0, 1, 0, 0))
+    w0, k0 = world(False, False)
+    scene = rta.Scene(w0, device_bvh=True)
+    first, s0 = scene.render(cam)
+    assert s0.rays_secondary == 0
+    w1, k1 = world(True, False)  # same structure, but the sphere now points at a glass material: two children per hit
+    with pytest.raises(rta.RtxError, match="material"):
+        scene.refit(w1)
+    assert scene.render(cam)[0].tobytes() == first.tobytes()
+    w2, k2 = world(False, True)
+    with pytest.raises(rta.RtxError, match="bounded"):
+        scene.refit(w2)
+    assert scene.render(cam)[0].tobytes() == first.tobytes()  # refused before anything was overwritten
+    scene.refit(w0)
+    assert scene.render(cam)[0].tobytes() == first.tobytes()
+    scene.close()
+
+
+def test_device_build_falls_back_to_the_linear_path_like_the_host_build():
+    """A triangle run that cannot be bounded (singular group transform) stays on the linear path with either builder:
+    same scene, same canvas, no error."""
+    obj = rta.ObjFile(_teapot_text(), bound=False)
+    obj.group.transform = su.scaling(1.0, 0.0, 1.0)
+    ball = st.Sphere(st.default_attrs())
+    w, keep = st.make_world([-6, 9, -8, 1], [1, 1, 1], groups=[obj.group], spheres=[ball])
+    cam = rta.camera(64, 48, 1.0, (0, 4, -11, 1), (0, 1.5, 0, 1), (0, 1, 0, 0))
+    host = rta.Scene(w)
+    a, sa = host.render(cam)
+    dev = rta.Scene(w, device_bvh=True)
+    b, sb = dev.render(cam)
+    assert a.tobytes() == b.tobytes() and sa.rays_total == sb.rays_total
+    assert not sa.kernel_flags & rta.RtxStats.KERNEL_BVH and not sb.kernel_flags & rta.RtxStats.KERNEL_BVH
+    host.close()
+    dev.close()
+
+
 # ---- rtx_opts.real = RTX_REAL_F64: the double-precision reporting instantiation (SURVEY fact 1, 8f-4) ----------
 
 def _oracle_f64():

@@ -1,6 +1,8 @@
 """rtx_render_device_static — the entry point that allocates nothing (its work buffers are a file-scope
 device array) — against rtx_render_device, through the C ABI, bit for bit: two calls in a row, the
-second with a smaller input, then another scene on the same array, and the size limit."""
+second with a smaller input, then another scene on the same array, and the size limit; and the property the
+entry point exists for: the first call on a fresh scene changes the device's free memory by nothing and can be
+captured into a HIP graph (where an allocation or a synchronisation is an error) and replayed."""
 import importlib
 
 import numpy as np
@@ -55,3 +57,42 @@ def test_static_work_set_equals_the_allocating_entry_point():
         fres.render_device_static(too_wide.camera, buf.data_ptr())
     for sc in (scene, mesh, fres):
         sc.close()
+
+
+def test_static_first_call_allocates_nothing_and_can_be_captured():
+    import torch
+
+    torch.cuda.init()
+    s = rta.Sample("glass_spheres", 320, 200)
+    scene = rta.Scene(s.world)  # fresh: no render call has grown a work set on it
+    cam = rta.flatten_camera(s.camera)
+    got32 = torch.full((200, 320, 3), 5.0, dtype=torch.float32, device="cuda")
+    got8 = torch.full((200, 320, 3), 77, dtype=torch.uint8, device="cuda")
+    ref32 = torch.zeros_like(got32)
+    ref8 = torch.zeros_like(got8)
+    stream = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    scene.render_device_static(cam, got32.data_ptr(), got8.data_ptr(), stream=stream.cuda_stream)
+    free1, _ = torch.cuda.mem_get_info()
+    torch.cuda.synchronize()
+    free2, _ = torch.cuda.mem_get_info()
+    assert free0 == free1 == free2, (free0, free1, free2)
+    scene.render_device(cam, ref32.data_ptr(), ref8.data_ptr(), stream=stream.cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(got32, ref32) and torch.equal(got8, ref8)
+    # under stream capture an allocation or a synchronisation is an error: capture the call, replay it twice
+    got32.fill_(1.0)
+    got8.fill_(3)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=stream):
+        scene.render_device_static(cam, got32.data_ptr(), got8.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    for _ in range(2):
+        got32.fill_(1.0)
+        got8.fill_(3)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(got32, ref32) and torch.equal(got8, ref8)
+    del g
+    scene.close()

@@ -82,7 +82,10 @@ for which in ("f32", "f64"):
     res[which] = {"add": round(add), "mul": round(mul), "fma": round(fma), "trans": round(tr), "valu": round(t["SQ_INSTS_VALU"] / nf),
                   "lanes_active": round(lanes, 3), "flop_slots": round(slots), "flops_active_lanes": round(slots * lanes), "launches": len(per)}
     print(which, res[which])
+import os
+bid = "gpurun_out/%s/build_id.txt" % tag  # written on the GPU box by tools/profile_round.sh
 json.dump({"what": "hardware flop-instruction counters of the plain k_trace_shade launches of one composite 3840x2160 frame "
                    "(rocprofv3 --pmc, tools/flop_counters.sh)", "frame": "composite 3840x2160", "f32": res["f32"], "f64": res["f64"],
+           "library_build": open(bid).read().strip() if os.path.exists(bid) else None,
            "unit": "wave-instructions per frame (add, mul, fma, trans, valu); flops = 64 x (add + mul + 2 fma + trans)"},
           open("profiles/%s_flops.json" % tag, "w"), indent=1)

@@ -5,6 +5,7 @@ set -e
 tag=$1
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
+python3 -c "import importlib,sys; sys.path.insert(0,'$GRAFT_REPO_ROOT'); print(importlib.import_module('ray-tracer_amd').build_id())" > $out/build_id.txt
 cd /tmp && export TMPDIR=/tmp
 # 1. the bench command under --kernel-trace --stats (per-kernel averages must agree with bench.py's HIP events).
 #    --headline-only: the other legs (D2H loop, f64 report, other configurations) launch the same kernel instantiations

@@ -62,8 +62,11 @@ open(os.path.join(dst, tag + "_pmc_composite4k.txt"), "w").write(
     "(two plain frames = 12 'k_trace_shade plain' launches, then one statistics frame = 6 'k_trace_shade stats' launches);\n"
     "FETCH_SIZE / WRITE_SIZE in KB as reported (FETCH_SIZE not yet doubled)\n" + "\n".join(lines) + "\n")
 bytes_all = (2.0 * traffic["fetch_kb"] + traffic["write_kb"]) * 1024.0
+bid_path = os.path.join(src, "build_id.txt")
+build_id = open(bid_path).read().strip() if os.path.exists(bid_path) else None  # written on the GPU box by profile_round.sh
 out = {
     "what": "HBM bytes moved by the plain k_trace_shade launches of composite 3840x2160 frames",
+    "library_build": build_id,
     "frame": "composite 3840x2160",
     "fetch_size_kb": traffic["fetch_kb"], "write_size_kb": traffic["write_kb"], "launches": traffic["launches"],
     "correction": "bytes = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 FETCH_SIZE counts 128-B requests as 64 B, MI355X_MICROARCH.md HBM section)",
