@@ -651,7 +651,9 @@ void launch_trace(const rtx_scene* s, const f32::Params& p, uint32_t level, uint
     const TraceKernel k = (p.book && track) ? book_kernel<GEN>(p.has_bvh != 0)
                           : (p.twins && track) ? twin_kernel<GEN>(p.has_bvh != 0)
                                                : trace_kernel<GEN>(track, p.tab_mode, p.canon != 0, p.has_bvh != 0, stats);
-    hipLaunchKernelGGL(k, dim3(blocks), dim3(256), p.lds_bytes, st, p, level);
+    const bool stash = stash_enabled(GEN, p.book && track, p.twins && track && !p.book);
+    const uint32_t lds = p.lds_bytes + (stash ? stash_bytes_per_block(track, (int)p.tab_mode) : 0u);
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(256), lds, st, p, level);
 }
 
 template <bool GEN>
@@ -691,7 +693,8 @@ int resident_blocks(const rtx_scene* s, const f32::Params& p) {
 template <bool GEN>
 int resident_blocks(const rtx_scene* s, uint32_t tab_mode, uint32_t lds_bytes, bool canon, bool bvh) {
     int n = 0;
-    const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_kernel<GEN>(s->track_n1, tab_mode, canon, bvh), 256, lds_bytes);
+    const uint32_t stash = stash_enabled(GEN, false, false) ? stash_bytes_per_block(s->track_n1, (int)tab_mode) : 0u;
+    const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_kernel<GEN>(s->track_n1, tab_mode, canon, bvh), 256, lds_bytes + stash);
     return (e == hipSuccess && n > 0) ? n : 4;
 }
 

@@ -4,8 +4,16 @@
 // there is no CPU fallback, so without a HIP device this exits non-zero with the library's
 // message.
 //
-//     render_sample <name> [width height] [out.ppm]
+//     render_sample <name> [width height] [out.ppm] [--gpus N] [--real f32|f64] [--containers v1|book] [--rows-quirk on|off]
 //
+// The reference hard-codes all of these per sample (samples/teapot.zig:30-31, src/world.zig:20, src/camera.zig:87);
+// here they are the switches SURVEY section 5 lists:
+//   --gpus N           GPUs the frame is spread over (default: every visible one, like rt_render; rtx_multi_* with two
+//                      strip sets per GPU when N > 1)
+//   --real f32|f64     f32 (default) is the reference's arithmetic and the parity mode; f64 is the reporting instantiation
+//   --containers v1|book   the n1/n2 container walk: the reference as written (default) or the book's (what the
+//                      reference's shipped refractive images were rendered with)
+//   --rows-quirk on|off    on (default): only 8 * floor(H / 8) rows are rendered, as src/camera.zig:87-88 does
 // `teapot` and `composite` read ./teapot.obj like samples/teapot.zig:7 does.
 #include <cstdio>
 #include <cstdlib>
@@ -16,15 +24,38 @@
 
 #include "../ray-tracer_amd/host/rt.hpp"
 
+namespace {
+int usage(const char* argv0) {
+    std::fprintf(stderr, "usage: %s <sample> [width height] [out.ppm] [--gpus N] [--real f32|f64] [--containers v1|book] [--rows-quirk on|off]\n", argv0);
+    return 2;
+}
+}  // namespace
+
 int main(int argc, char** argv) {
-    if (argc < 2) {
-        std::fprintf(stderr, "usage: %s <sample> [width height] [out.ppm]\n", argv[0]);
-        return 2;
+    // switches first: what is left are the positional arguments
+    std::vector<std::string> pos;
+    int gpus = 0;
+    rtx_opts opts{};
+    opts.rows_quirk = 1;  // src/camera.zig:87-88
+    for (int i = 1; i < argc; ++i) {
+        const std::string a = argv[i];
+        if (a.rfind("--", 0) != 0) {
+            pos.push_back(a);
+            continue;
+        }
+        if (i + 1 >= argc) return usage(argv[0]);
+        const std::string v = argv[++i];
+        if (a == "--gpus") gpus = std::atoi(v.c_str());
+        else if (a == "--real" && (v == "f32" || v == "f64")) opts.real = v == "f64" ? RTX_REAL_F64 : RTX_REAL_F32;
+        else if (a == "--containers" && (v == "v1" || v == "book")) opts.containers = v == "book" ? RTX_CONTAINERS_BOOK : RTX_CONTAINERS_V1;
+        else if (a == "--rows-quirk" && (v == "on" || v == "off")) opts.rows_quirk = v == "on" ? 1u : 0u;
+        else return usage(argv[0]);
     }
-    const std::string name = argv[1];
-    const uint32_t width = argc > 3 ? (uint32_t)std::strtoul(argv[2], nullptr, 10) : 0u;
-    const uint32_t height = argc > 3 ? (uint32_t)std::strtoul(argv[3], nullptr, 10) : 0u;
-    const std::string out = argc > 4 ? argv[4] : (argc == 3 ? argv[2] : name + ".ppm");
+    if (pos.empty() || gpus < 0) return usage(argv[0]);
+    const std::string name = pos[0];
+    const uint32_t width = pos.size() > 2 ? (uint32_t)std::strtoul(pos[1].c_str(), nullptr, 10) : 0u;
+    const uint32_t height = pos.size() > 2 ? (uint32_t)std::strtoul(pos[2].c_str(), nullptr, 10) : 0u;
+    const std::string out = pos.size() > 3 ? pos[3] : (pos.size() == 2 ? pos[1] : name + ".ppm");
 
     rt_sample* s = nullptr;
     if (name == "composite") {
@@ -42,8 +73,30 @@ int main(int argc, char** argv) {
     }
     const rt_camera* cam = rt_sample_camera(s);
     rt::Canvas canvas(cam->horizontal_size, cam->vertical_size);
-    rt_ray_counts counts{};
-    const int rc = rt_render(cam, rt_sample_world(s), canvas.pixels.data(), &counts);
+    // What rt_render does (flatten, upload, render, copy back), spelled out so that the switches reach rtx_opts.
+    rt_flat_scene* flat = nullptr;
+    int rc = rt_flatten(rt_sample_world(s), &flat);
+    rtx_camera fcam;
+    rt_flatten_camera(cam, &fcam);
+    rtx_stats stats{};
+    if (rc == 0) {
+        const int visible = rtx_device_count();
+        if (gpus == 0 || gpus > visible) gpus = visible;
+        if (gpus > 1) {
+            rtx_multi* multi = nullptr;
+            std::vector<int> devices;
+            for (int d = 0; d < gpus; ++d) devices.push_back(d);
+            rc = rtx_multi_create(rt_flat_desc(flat), devices.data(), (uint32_t)devices.size(), &multi);
+            if (rc == 0) rc = rtx_multi_render(multi, &fcam, &opts, 2, canvas.pixels.data(), nullptr, &stats);
+            rtx_multi_destroy(multi);
+        } else {
+            rtx_scene* scene = nullptr;
+            rc = rtx_scene_create(rt_flat_desc(flat), 0, &scene);  // fails with RTX_E_NO_DEVICE when there is no GPU
+            if (rc == 0) rc = rtx_render(scene, &fcam, &opts, canvas.pixels.data(), &stats);
+            rtx_scene_destroy(scene);
+        }
+        rt_flat_free(flat);
+    }
     rt_sample_destroy(s);
     if (rc != 0) {
         std::fprintf(stderr, "render failed (%d): %s\n", rc, rtx_last_error());
@@ -51,8 +104,9 @@ int main(int argc, char** argv) {
     }
     std::ofstream ppm(out, std::ios::binary);
     canvas.toPPM(ppm);
-    std::printf("%s %ux%u -> %s  rays: %llu primary, %llu shadow, %llu secondary\n", name.c_str(), canvas.width,
-                canvas.height, out.c_str(), (unsigned long long)counts.primary, (unsigned long long)counts.shadow,
-                (unsigned long long)counts.secondary);
+    std::printf("%s %ux%u -> %s  rays: %llu primary, %llu shadow, %llu secondary  (%d GPU%s, %s, containers %s, rows quirk %s)\n", name.c_str(),
+                canvas.width, canvas.height, out.c_str(), (unsigned long long)stats.rays_primary, (unsigned long long)stats.rays_shadow,
+                (unsigned long long)stats.rays_secondary, gpus, gpus == 1 ? "" : "s", opts.real == RTX_REAL_F64 ? "f64" : "f32",
+                opts.containers == RTX_CONTAINERS_BOOK ? "book" : "v1", opts.rows_quirk ? "on" : "off");
     return ppm ? 0 : 1;
 }

@@ -550,6 +550,22 @@ def test_render_sample_program_writes_the_reference_ppm(tmp_path):
     img = ppm.read(out)
     assert open(out, "rb").read(15) == b"P3\n512 512\n255\n"
     assert ppm.within_tolerance(img, _golden("skewed_triangle"))
+    # the switches of SURVEY section 5: book containers reproduce the Scene API's book render, the rows quirk can be
+    # switched off (sphere_world 100x70: 64 of 70 rows with it), f64 runs, a bad value is a usage error
+    book = str(tmp_path / "glass_book.ppm")
+    r = subprocess.run([exe, "glass_spheres", "64", "64", book, "--containers", "book", "--gpus", "1"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "containers book" in r.stdout, r.stderr
+    s = rta.Sample("glass_spheres", 64, 64)
+    scene = rta.Scene(s.world)
+    assert np.array_equal(ppm.read(book), rta.to_ppm_bytes(scene.render(s.camera, book=True)[0]))
+    assert not np.array_equal(ppm.read(book), rta.to_ppm_bytes(scene.render(s.camera)[0]))
+    scene.close()
+    full = str(tmp_path / "all_rows.ppm")
+    r = subprocess.run([exe, "sphere_world", "100", "70", full, "--rows-quirk", "off", "--real", "f64"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "7000 primary" in r.stdout and "f64" in r.stdout, r.stderr
+    assert ppm.read(full)[64:].any()
+    r = subprocess.run([exe, "sphere_world", "--real", "f16"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "usage" in r.stderr
 
 
 # ---- BASELINE.json configs[2..4] at their full sizes ---------------------------------------
