@@ -912,6 +912,12 @@ void lds_plan(uint32_t n_shapes, uint32_t n_materials, uint32_t n_patterns, uint
     const size_t small = sizeof(rtx_material) * n_materials + sizeof(rtx_pattern) * n_patterns + sizeof(HitRec) * n_shapes;
     const size_t all = small + sizeof(rtx_shape) * n_shapes;
     *tab_mode = all <= kLdsSceneBytes ? (uint32_t)kTabAll : (small <= kLdsSceneBytes ? (uint32_t)kTabHit : (uint32_t)kTabGlobal);
+    static const int cap = [] {  // RTX_TAB_MODE=2 / 0: at most that much in LDS (experiments: what a table layout costs)
+        const char* e = getenv("RTX_TAB_MODE");
+        return e ? atoi(e) : -1;
+    }();
+    if (cap == (int)kTabGlobal) *tab_mode = (uint32_t)kTabGlobal;
+    if (cap == (int)kTabHit && *tab_mode == (uint32_t)kTabAll) *tab_mode = (uint32_t)kTabHit;
     *lds_bytes = *tab_mode == (uint32_t)kTabAll ? (uint32_t)all : (*tab_mode == (uint32_t)kTabHit ? (uint32_t)small : 0u);
 }
 
@@ -923,7 +929,8 @@ void fill_scene_params(const rtx_scene* s, P& p, uint32_t depth) {
     p.bvh_nodes = s->d_bvh_nodes;
     p.bvh_tris = s->d_bvh_tris;
     p.twins = s->d_twins;
-    p.has_bvh = s->n_bvh_nodes ? 1u : 0u;
+    static const bool force_bvh = getenv("RTX_FORCE_BVH_KERNEL") != nullptr;  // experiments: the tree-walking variants on a scene without a tree
+    p.has_bvh = (s->n_bvh_nodes || force_bvh) ? 1u : 0u;
     p.finite_schlick = s->finite_schlick ? 1u : 0u;
     p.shadow_skip = s->shadow_skip ? 1u : 0u;  // render_impl_t clears it for rtx_opts.all_shadows
     p.materials = s->d_materials;
