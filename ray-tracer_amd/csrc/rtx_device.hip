@@ -659,18 +659,24 @@ void launch_trace(const rtx_scene* s, const f32::Params& p, uint32_t level, uint
 template <bool GEN>
 int resident_blocks(const rtx_scene* s, uint32_t tab_mode, uint32_t lds_bytes, bool canon, bool bvh);
 
-// The f64 reporting instantiation (rtx_opts.real = RTX_REAL_F64) exists in the plainest form only: tables in
-// global memory, four-lane arithmetic, no event tallies, the reference's own container walk.
+// The f64 reporting instantiation (rtx_opts.real = RTX_REAL_F64): the four-lane variants with every table in global memory,
+// and — for frames that keep w canonical — the variants without the w lanes, with the hit records in LDS where they fit.
+// No event tallies, the reference's own container walk.
 using TraceKernel64 = void (*)(const f64::Params, const uint32_t);
+template <int TAB, bool GEN, bool C>
+TraceKernel64 trace_kernel64_t(bool track, bool bvh) {
+    if (track) return bvh ? f64::k_trace_shade<TAB, GEN, true, C, true, false> : f64::k_trace_shade<TAB, GEN, true, C, false, false>;
+    return bvh ? f64::k_trace_shade<TAB, GEN, false, C, true, false> : f64::k_trace_shade<TAB, GEN, false, C, false, false>;
+}
 template <bool GEN>
-TraceKernel64 trace_kernel64(bool track, bool bvh) {
-    if (track) return bvh ? f64::k_trace_shade<kTabGlobal, GEN, true, false, true, false> : f64::k_trace_shade<kTabGlobal, GEN, true, false, false, false>;
-    return bvh ? f64::k_trace_shade<kTabGlobal, GEN, false, false, true, false> : f64::k_trace_shade<kTabGlobal, GEN, false, false, false, false>;
+TraceKernel64 trace_kernel64(bool track, bool bvh, bool canon, uint32_t tab) {
+    if (!canon) return trace_kernel64_t<kTabGlobal, GEN, false>(track, bvh);
+    return tab == (uint32_t)kTabHit ? trace_kernel64_t<kTabHit, GEN, true>(track, bvh) : trace_kernel64_t<kTabGlobal, GEN, true>(track, bvh);
 }
 template <bool GEN>
 void launch_trace(const rtx_scene* s, const f64::Params& p, uint32_t level, uint32_t blocks, hipStream_t st, bool) {
     const bool track = s->track_n1 && !(level == p.depth && s->finite_schlick);
-    hipLaunchKernelGGL(trace_kernel64<GEN>(track, p.has_bvh != 0), dim3(blocks), dim3(256), 0, st, p, level);
+    hipLaunchKernelGGL(trace_kernel64<GEN>(track, p.has_bvh != 0, p.canon != 0, p.tab_mode), dim3(blocks), dim3(256), p.lds_bytes, st, p, level);
 }
 void launch_combine(const f32::Params& p, uint32_t level, uint32_t blocks, hipStream_t st) {
     hipLaunchKernelGGL(f32::k_combine, dim3(blocks), dim3(256), 0, st, p, level);
@@ -683,7 +689,7 @@ void launch_combine(const f64::Params& p, uint32_t level, uint32_t blocks, hipSt
 template <bool GEN>
 int resident_blocks(const rtx_scene* s, const f64::Params& p) {
     int n = 0;
-    const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_kernel64<GEN>(s->track_n1, p.has_bvh != 0), 256, 0);
+    const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_kernel64<GEN>(s->track_n1, p.has_bvh != 0, p.canon != 0, p.tab_mode), 256, p.lds_bytes);
     return (e == hipSuccess && n > 0) ? n : 2;
 }
 template <bool GEN>
@@ -1167,9 +1173,15 @@ int render_impl_t(rtx_scene* s, const rtx_camera* cam, const rtx_opts* opts, flo
     if (kF64) {
         if (p.book) return fail(RTX_E_INVALID, "RTX_REAL_F64 renders with the reference's own container walk only");
         if (fixed) return fail(RTX_E_INVALID, "rtx_render_device_static renders in f32 only");
-        p.canon = 0u;
-        p.tab_mode = (uint32_t)kTabGlobal;
-        p.lds_bytes = 0u;
+        // canonical frames: hit records, materials and patterns in LDS if they fit (the 160-byte shape records stay in
+        // global memory: TAB 1 is not instantiated over double); four-lane frames: everything in global memory
+        if (!p.canon || p.tab_mode == (uint32_t)kTabGlobal) {
+            p.tab_mode = (uint32_t)kTabGlobal;
+            p.lds_bytes = 0u;
+        } else {
+            p.tab_mode = (uint32_t)kTabHit;
+            p.lds_bytes = (uint32_t)(sizeof(rtx_material) * s->n_materials + sizeof(rtx_pattern) * s->n_patterns + sizeof(HitRec) * s->n_shapes);
+        }
     }
     for (int l = 0; l < lanes && !fixed; ++l) {
         rc = ensure_work(s, &s->ws[l], cap, p.canon == 0, kF64 ? 2u : 1u);
