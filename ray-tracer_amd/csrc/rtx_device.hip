@@ -1213,9 +1213,11 @@ int render_impl_t(rtx_scene* s, const rtx_camera* cam, const rtx_opts* opts, flo
     // caller's stream itself carries the work).
     hipStream_t lane_stream[kLanes];
     for (int l = 0; l < lanes; ++l) lane_stream[l] = lanes == 1 ? st : s->ws[l].stream;
+    static const bool trace_lanes = getenv("RTX_TRACE_LANES") != nullptr;  // experiments: host-side progress of a two-lane frame on stderr
     if (lanes > 1) {
         HIP_TRY(hipEventRecord(s->ev_fork, st));
         for (int l = 0; l < lanes; ++l) HIP_TRY(hipStreamWaitEvent(lane_stream[l], s->ev_fork, 0));
+        if (trace_lanes) fprintf(stderr, "rtx lanes: forked %d lanes\n", lanes);
     }
 
     uint32_t batch = 0;
@@ -1234,6 +1236,7 @@ int render_impl_t(rtx_scene* s, const rtx_camera* cam, const rtx_opts* opts, flo
             HIP_TRY(hipEventRecord(s->ws[l].done, lane_stream[l]));
             HIP_TRY(hipStreamWaitEvent(st, s->ws[l].done, 0));
         }
+        if (trace_lanes) fprintf(stderr, "rtx lanes: joined (%u batches queued)\n", batch);
     }
     if (d_rgb8) {
         const size_t n = out_rows * W * 3;
@@ -1500,7 +1503,18 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out) {
     for (WorkSet& w : s->ws) {
         HIP_TRY_S(hipMalloc(&w.d_counters, 2 * sizeof(Counters)));
         HIP_TRY_S(hipMalloc(&w.d_totals, sizeof(Totals)));
+#ifdef RTX_EXP_LANE_PRIORITY
+        // Experiment only (tools/build_variant.sh prio -DRTX_EXP_LANE_PRIORITY): the two lane streams at the two ends of the
+        // priority range, which puts them on hardware queues of different pools.  Round 2 saw bench.py's process hang with
+        // this; DESIGN.md 5c records what the bounded re-run of round 3 found.
+        {
+            int least = 0, greatest = 0;
+            HIP_TRY_S(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            HIP_TRY_S(hipStreamCreateWithPriority(&w.stream, hipStreamNonBlocking, (&w == &s->ws[0]) ? greatest : least));
+        }
+#else
         HIP_TRY_S(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
+#endif
         HIP_TRY_S(hipEventCreateWithFlags(&w.done, hipEventDisableTiming));
     }
 #undef HIP_TRY_S
