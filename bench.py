@@ -22,6 +22,13 @@ Time is the max over ranks between two barrier+synchronize pairs; all gathers ar
 With fewer visible GPUs than ranks the run is a REHEARSAL (all ranks on GPU 0, gloo): it checks the N > 1
 code path (what rank 0 received equals the whole-frame render) and says "rehearsal": true — not a measurement.
 
+N = 1 keeps two frames in flight by default (--frames-in-flight): frame k runs through work set k % 2 of the scene
+(rtx_opts.work_set: its own ray queues, nodes and counters) on stream k % 2 into canvases of its own, so the deep levels of one
+frame — few rays, latency-bound, 58-62 % of the VALU issue slots used — share the chip with the next frame's level 0.  `value` and
+`ms_per_step` are that loop's throughput; `config.frame_ms_one_at_a_time` is the same frame with nothing else in flight.  Timed
+steps that carry per-launch HIP events run alone (the other slot is drained first and waits), so `roofline` prices a kernel by
+itself; `--headline-only` (the command profiles/ traces) keeps one frame in flight throughout.
+
 Also in the same JSON line (N = 1):
 * `roofline` for the dominant kernel, k_trace_shade: algorithmic flops = SURVEY §8d's table x the
   device's own event counts (rtx_stats: shape tests by type, gate tests, BVH box and triangle tests,
@@ -52,7 +59,7 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 WIDTH, HEIGHT = 3840, 2160
 STRIP_ROWS = 16
-EVENT_EVERY = 10  # timed steps whose kernel launches are bracketed by HIP events (roofline.avg_launch_ms)
+EVENT_EVERY = 20  # timed steps whose kernel launches are bracketed by HIP events (roofline.avg_launch_ms)
 VALU_PEAK_FMA_TFLOPS = 78.6     # the contract denominator: 256 CU x 4 SIMD x 16 lanes x 2.4 GHz x 2 (FMA), unpacked
 VALU_PEAK_UNFUSED_TFLOPS = 39.3  # one flop per VALU instruction: contraction is forbidden by parity (measured 38.7 T lane-ops/s,
                                  # profiles/r01_m_valu_rate.txt)
@@ -219,6 +226,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--frames-in-flight", type=int, default=2,
+                    help="N = 1: frame k runs through work set k %% F of the scene (rtx_opts.work_set) on stream k %% F, so the deep, "
+                         "latency-bound levels of one frame share the chip with the next frame's level 0; 1 = one frame at a time")
     ap.add_argument("--lanes", type=int, default=1, help="rtx_opts.lanes for the timed frames (2 is an experiment: see rtx.h)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline legs")
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configs")
@@ -235,6 +245,8 @@ def main():
                     help="N > 1: deal whole frames to the ranks (weak scaling) instead of splitting every frame into strips")
     args = ap.parse_args()
     n = args.gpus
+    if args.headline_only:
+        args.frames_in_flight = 1  # every launch of the run is then a kernel running alone: what the rocprofv3 averages under profiles/ are of
     if n > 1 and args.in_process:
         sys.exit(in_process(args))
     if n > 1 and "WORLD_SIZE" not in os.environ:
@@ -288,6 +300,12 @@ def main():
         gdev = torch.device("cpu") if rehearse else dev
         whole_slots = [[torch.zeros(rgb8[0].shape, dtype=torch.uint8, device=gdev) for _ in range(n)] for _ in range(2)] if rank == 0 else None
     pending = {}
+    # N = 1: F frames in flight, each on a stream, canvases and a work set of its own (slot 0 is the stream and the canvases above)
+    F = max(1, min(3, args.frames_in_flight)) if n == 1 else 1
+    slot_streams = [tstream] + [torch.cuda.Stream(device=dev) for _ in range(F - 1)]
+    slot_rgb = [rgb] + [torch.zeros_like(rgb) for _ in range(F - 1)]
+    slot_rgb8 = [rgb8[0]] + [torch.zeros_like(rgb8[0]) for _ in range(F - 1)]
+    slot_done = [torch.cuda.Event() for _ in range(F)]
 
     def finish(b):
         if exchange is not None:
@@ -298,6 +316,20 @@ def main():
                 work.wait()
 
     def frame(k, profile):
+        if F > 1:
+            # A frame that carries per-launch events runs alone (slot 0 waits for the others, the others wait for it): its
+            # kernels must not share the chip with another frame's if their durations are to be those of a kernel.
+            slot = 0 if profile else k % F
+            if profile:
+                for other in range(1, F):
+                    slot_streams[0].wait_event(slot_done[other])
+            scene.render_device(fcam, slot_rgb[slot].data_ptr(), slot_rgb8[slot].data_ptr(), stream=slot_streams[slot].cuda_stream,
+                                profile=profile, lanes=args.lanes, work_set=slot)
+            slot_done[slot].record(slot_streams[slot])
+            if profile:
+                for other in range(1, F):
+                    slot_streams[other].wait_event(slot_done[0])
+            return
         b = k & 1
         finish(b)  # set b is free again once its last gather has landed
         scene.render_device(fcam, rgb.data_ptr(), rgb8[b].data_ptr(), stream=stream, strips=strips, compact_rows=split,
@@ -330,6 +362,15 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     prof = scene.profile_collect()
+    frame_ms_alone = None
+    if n == 1 and F > 1:  # the same frames one at a time (untimed extra): what a single frame takes from first launch to last
+        torch.cuda.synchronize()
+        t_a = time.perf_counter()
+        for k in range(20):
+            scene.render_device(fcam, rgb.data_ptr(), rgb8[0].data_ptr(), stream=stream, lanes=args.lanes)
+        torch.cuda.synchronize()
+        frame_ms_alone = (time.perf_counter() - t_a) / 20 * 1e3
+        assert all(torch.equal(slot_rgb8[0], x) for x in slot_rgb8[1:]), "the canvases of the frame slots differ"
 
     if rehearse and n > 1 and rank == 0:  # what arrived must be the whole-frame render, byte for byte
         whole = rta.to_ppm_bytes(scene.render(fcam)[0])[None]
@@ -479,10 +520,13 @@ def main():
                                 WIDTH, HEIGHT, "one frame" if frames_per_step == 1 else "%d frames (one per rank)" % n),
                 "rays_per_step": int(rays_step),
                 "frame_ms": dt / args.steps * 1e3 / frames_per_step,
+                "frames_in_flight": F,
+                "frame_ms_one_at_a_time": frame_ms_alone,
                 "kernel_variant": {"canonical_w": bool(stats.kernel_flags & 1), "bvh": bool(stats.kernel_flags & 2),
                                    "lds_tables": bool(stats.kernel_flags & 4), "track_n1": bool(stats.kernel_flags & 8),
                                    "lds_hit_records": bool(stats.kernel_flags & 16)},
-                "parallelism": "1 GPU" if n == 1 else (
+                "parallelism": ("1 GPU, %d frames in flight (frame k on work set and stream k %% %d: a frame's deep, latency-bound levels share "
+                                "the chip with the next frame's level 0; frames with per-launch events run alone)" % (F, F) if F > 1 else "1 GPU") if n == 1 else (
                     "%d ranks x 16-row strips of every frame, RCCL gather + re-interleave of the u8 strips on rank 0, "
                     "overlapped with the next step" % n if split
                     else "%d ranks x whole frames, one RCCL gather of the u8 canvases per step on rank 0, overlapped "

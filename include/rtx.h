@@ -16,7 +16,7 @@
  * Conventions: every function returns 0 on success or a negative RTX_E_* code and never
  * throws; rtx_last_error() gives the thread-local message; the caller owns every host
  * buffer it passes; the library owns all device memory; one render in flight per
- * rtx_scene.  Plain pointers and sizes only — no C++/torch types cross this boundary.
+ * rtx_scene and work set (rtx_opts.work_set).  Plain pointers and sizes only — no C++/torch types cross this boundary.
  */
 #ifndef RTX_H
 #define RTX_H
@@ -170,6 +170,12 @@ typedef struct rtx_opts {
     uint32_t all_shadows;  /* 1: traverse every isShadowed call, also where the light is behind the surface and the
                               answer cannot reach the colour (A/B check; same canvas, same counts but
                               rtx_stats.shadow_rays_skipped == 0, slower) */
+    uint32_t work_set;     /* 0..2: which of the scene's independent sets of work buffers (ray queues, ray-tree nodes,
+                              counters) this frame runs through.  Frames on different sets, queued on different streams,
+                              may be in flight together — the deep, latency-bound levels of one frame then share the chip
+                              with the next frame's level 0 (headline frame loop: 1.40 -> 1.21 ms per frame with two in
+                              flight); frames on the same set must be ordered by the caller (one stream).  Needs lanes <= 1
+                              and profile == 0 unless 0; every set is allocated on first use */
 } rtx_opts;
 
 /* rtx_opts.real.  F32 (default) is the reference's own arithmetic (src/tuple.zig:6: Tuple = @Vector(4, f32)) and

@@ -68,7 +68,7 @@ class RtxCamera(C.Structure):
 class RtxOpts(C.Structure):
     _fields_ = [("depth", u32), ("rows_quirk", u32), ("batch_pixels", u32), ("strip_rows", u32),
                 ("strip_count", u32), ("strip_index", u32), ("compact_rows", u32), ("profile", u32),
-                ("no_bvh", u32), ("full_w", u32), ("lanes", u32), ("containers", u32), ("real", u32), ("all_shadows", u32)]
+                ("no_bvh", u32), ("full_w", u32), ("lanes", u32), ("containers", u32), ("real", u32), ("all_shadows", u32), ("work_set", u32)]
 
 
 class RtxStats(C.Structure):
@@ -374,7 +374,7 @@ class Scene:
                        batch_pixels=kw.get("batch_pixels", 0), compact_rows=1 if kw.get("compact_rows", False) else 0,
                        profile=1 if kw.get("profile", False) else 0, no_bvh=1 if kw.get("no_bvh", False) else 0,
                        full_w=1 if kw.get("full_w", False) else 0, lanes=kw.get("lanes", 0), real=1 if kw.get("f64", False) else 0,
-                       all_shadows=1 if kw.get("all_shadows", False) else 0)
+                       all_shadows=1 if kw.get("all_shadows", False) else 0, work_set=kw.get("work_set", 0))
         if kw.get("strips") is not None:
             opts.strip_rows, opts.strip_count, opts.strip_index = kw["strips"]
         stats = RtxStats() if want_stats else None

@@ -328,7 +328,8 @@ __global__ void k_quantise(const float* rgb, uint8_t* out, size_t n, size_t n4) 
 
 // ---------------------------------------------------------------------- host side
 
-constexpr int kLanes = 2;
+constexpr int kLanes = 2;     // a frame can be cut into this many halves that run on streams of their own (rtx_opts.lanes)
+constexpr int kWorkSets = 3;  // independent sets of work buffers per scene: as many frames can be in flight (rtx_opts.work_set)
 
 // One set of work buffers, sized for `cap_pixels` pixels per batch at depth kMaxDepth.
 struct WorkSet {
@@ -348,6 +349,7 @@ struct WorkSet {
     bool counters_dirty = true;    // d_counters are not known to be zero (see run_levels)
     hipStream_t stream = nullptr;  // lane stream (lane 0 of a single-lane frame runs on the caller's)
     hipEvent_t done = nullptr;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;  // bracket a frame rendered through this set (rtx_stats.ms_total)
 };
 
 // ---- work buffers that are never allocated: rtx_render_device_static --------------------------
@@ -425,12 +427,11 @@ struct rtx_scene {
     // Work buffers come in kLanes independent sets: the batches of one frame alternate between
     // them on two streams, so the kernels of one batch fill the tails (and the empty deep
     // levels) of the other's.
-    WorkSet ws[kLanes];
+    WorkSet ws[kWorkSets];
     WorkSet ws_static;  // pointers into this device's `scratch` (rtx_render_device_static); owns nothing
     hipEvent_t ev_fork = nullptr;
     float* d_canvas = nullptr;  // staging canvas for the host-output entry points
     size_t canvas_floats = 0;
-    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     int num_cus = 256;
     int resident_blocks[8][2] = {};  // k_trace_shade blocks per CU: [canonical + 2 * bvh + 4 * f64][0 queue-fed, 1 ray-generating]
     // profile = 1: pooled events bracketing each launch, pending until read back
@@ -1125,6 +1126,12 @@ int render_impl_t(rtx_scene* s, const rtx_camera* cam, const rtx_opts* opts, flo
     if (lanes > kLanes) return fail(RTX_E_INVALID, "lanes %d exceeds %d", lanes, kLanes);
     if (lanes == 0) lanes = 1;
     if (profile || plan.rows_local < 64u || fixed) lanes = 1;
+    // rtx_opts.work_set: which of the scene's sets of work buffers a single-lane frame runs through.  Frames on different
+    // sets (and different streams) may be in flight together; frames on one set must be ordered by their caller.
+    const int set0 = (int)((opts && !fixed) ? opts->work_set : 0u);
+    if (set0 >= kWorkSets) return fail(RTX_E_INVALID, "work_set %d: 0..%d", set0, kWorkSets - 1);
+    if (set0 != 0 && lanes > 1) return fail(RTX_E_INVALID, "work_set %d: a frame cut into lanes uses sets 0 and 1", set0);
+    if (set0 != 0 && profile) return fail(RTX_E_INVALID, "work_set %d: frames with per-launch events run through set 0", set0);
     if (lanes > 1) {
         const uint32_t half = ((plan.rows_local + (uint32_t)lanes - 1u) / (uint32_t)lanes + 7u) & ~7u;
         if (half < rows_per_batch) rows_per_batch = half;
@@ -1184,7 +1191,7 @@ int render_impl_t(rtx_scene* s, const rtx_camera* cam, const rtx_opts* opts, flo
         }
     }
     for (int l = 0; l < lanes && !fixed; ++l) {
-        rc = ensure_work(s, &s->ws[l], cap, p.canon == 0, kF64 ? 2u : 1u);
+        rc = ensure_work(s, &s->ws[set0 + l], cap, p.canon == 0, kF64 ? 2u : 1u);
         if (rc) return rc;
     }
     if (fixed) fixed->counters_dirty = true;  // the array is shared by every scene on this GPU and keeps the last call's contents
@@ -1205,7 +1212,7 @@ int render_impl_t(rtx_scene* s, const rtx_camera* cam, const rtx_opts* opts, flo
     p.compact_rows = compact ? 1u : 0u;
     p.canvas = d_rgb;
 
-    if (!fixed) HIP_TRY(hipEventRecord(s->ev_begin, st));
+    if (!fixed) HIP_TRY(hipEventRecord(s->ws[set0].ev_begin, st));
     // Canvas starts black (canvas.zig:23-25); rows never rendered stay black.  Every rendered
     // pixel is written exactly once, so only a canvas with unrendered rows needs the fill.
     if (!compact && plan.rows_local < H) HIP_TRY(hipMemsetAsync(d_rgb, 0, out_rows * W * 3 * sizeof(float), st));
@@ -1227,7 +1234,7 @@ int render_impl_t(rtx_scene* s, const rtx_camera* cam, const rtx_opts* opts, flo
         p.n_rows = n_rows;
         const uint32_t items = tiles_x * ((n_rows + 7u) / 8u) * 64u;
         const int l = (int)(batch % (uint32_t)lanes);
-        rc = run_levels<true>(s, fixed ? *fixed : s->ws[l], p, cap, items, lane_stream[l], profile, batch < (uint32_t)lanes, stats != nullptr);
+        rc = run_levels<true>(s, fixed ? *fixed : s->ws[set0 + l], p, cap, items, lane_stream[l], profile, batch < (uint32_t)lanes, stats != nullptr);
         if (rc) return rc;
     }
     const int lanes_used = batch < (uint32_t)lanes ? (int)batch : lanes;
@@ -1243,13 +1250,13 @@ int render_impl_t(rtx_scene* s, const rtx_camera* cam, const rtx_opts* opts, flo
         const bool aligned = (reinterpret_cast<uintptr_t>(d_rgb) % 16u == 0u) && (reinterpret_cast<uintptr_t>(d_rgb8) % 4u == 0u);
         hipLaunchKernelGGL(k_quantise, dim3(2048), dim3(256), 0, st, d_rgb, d_rgb8, n, aligned ? n / 4 : (size_t)0);
     }
-    if (!fixed) HIP_TRY(hipEventRecord(s->ev_end, st));
+    if (!fixed) HIP_TRY(hipEventRecord(s->ws[set0].ev_end, st));
     HIP_TRY(hipGetLastError());
 
     if (stats) {
         std::memset(stats, 0, sizeof *stats);
         Totals t{}, part[kLanes];
-        for (int l = 0; l < lanes_used; ++l) HIP_TRY(hipMemcpyAsync(&part[l], s->ws[l].d_totals, sizeof(Totals), hipMemcpyDeviceToHost, st));
+        for (int l = 0; l < lanes_used; ++l) HIP_TRY(hipMemcpyAsync(&part[l], s->ws[set0 + l].d_totals, sizeof(Totals), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         for (int l = 0; l < lanes_used; ++l) {
             for (int k = 0; k < kLevels; ++k) {
@@ -1288,7 +1295,7 @@ int render_impl_t(rtx_scene* s, const rtx_camera* cam, const rtx_opts* opts, flo
         stats->kernel_flags = (p.canon ? RTX_KERNEL_CANONICAL_W : 0u) | (p.has_bvh ? RTX_KERNEL_BVH : 0u) |
                               (p.tab_mode == (uint32_t)kTabAll ? RTX_KERNEL_LDS_TABLES : 0u) | (p.tab_mode == (uint32_t)kTabHit ? RTX_KERNEL_LDS_HIT_RECORDS : 0u) | (s->track_n1 ? RTX_KERNEL_TRACK_N1 : 0u) |
                               (kF64 ? RTX_KERNEL_F64 : 0u);
-        HIP_TRY(hipEventElapsedTime(&stats->ms_total, s->ev_begin, s->ev_end));
+        HIP_TRY(hipEventElapsedTime(&stats->ms_total, s->ws[set0].ev_begin, s->ws[set0].ev_end));
         if (profile) {
             rc = collect_profile(s, stats);
             if (rc) return rc;
@@ -1360,8 +1367,6 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out) {
     HIP_TRY_S(hipGetDeviceProperties(&prop, device));
     s->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     HIP_TRY_S(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
-    HIP_TRY_S(hipEventCreate(&s->ev_begin));
-    HIP_TRY_S(hipEventCreate(&s->ev_end));
 
     s->n_shapes = desc->n_shapes;
     s->n_nodes = desc->n_nodes;
@@ -1516,6 +1521,8 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out) {
         HIP_TRY_S(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
 #endif
         HIP_TRY_S(hipEventCreateWithFlags(&w.done, hipEventDisableTiming));
+        HIP_TRY_S(hipEventCreate(&w.ev_begin));
+        HIP_TRY_S(hipEventCreate(&w.ev_end));
     }
 #undef HIP_TRY_S
     *out = s;
@@ -1532,6 +1539,8 @@ void rtx_scene_destroy(rtx_scene* s) {
         if (w.d_counters) (void)hipFree(w.d_counters);
         if (w.d_totals) (void)hipFree(w.d_totals);
         if (w.done) (void)hipEventDestroy(w.done);
+        if (w.ev_begin) (void)hipEventDestroy(w.ev_begin);
+        if (w.ev_end) (void)hipEventDestroy(w.ev_end);
         if (w.stream) (void)hipStreamDestroy(w.stream);
     }
     if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
@@ -1548,8 +1557,6 @@ void rtx_scene_destroy(rtx_scene* s) {
     if (s->d_materials) (void)hipFree(s->d_materials);
     if (s->d_patterns) (void)hipFree(s->d_patterns);
     for (hipEvent_t e : s->prof_events) (void)hipEventDestroy(e);
-    if (s->ev_begin) (void)hipEventDestroy(s->ev_begin);
-    if (s->ev_end) (void)hipEventDestroy(s->ev_end);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
 }

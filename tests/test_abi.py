@@ -43,7 +43,7 @@ def test_struct_sizes_match_the_headers():
     assert C.sizeof(rta.RtxPattern) == 96
     assert C.sizeof(rta.RtxNode) == 48
     assert C.sizeof(rta.RtxCamera) == 20 + 64
-    assert C.sizeof(rta.RtxOpts) == 56
+    assert C.sizeof(rta.RtxOpts) == 60
     # and every mirror against the sizes the library itself was compiled with
     mirrors = [rta.RtxShape, rta.RtxMaterial, rta.RtxPattern, rta.RtxNode, rta.RtxSceneDesc, rta.RtxCamera, rta.RtxOpts, rta.RtxStats]
     assert [C.sizeof(m) for m in mirrors] == [rta.lib().rtx_struct_size(k) for k in range(len(mirrors))]

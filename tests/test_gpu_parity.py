@@ -285,6 +285,32 @@ def test_fresnel_full_size_sampled_rows_match_oracle():
     scene.close()
 
 
+def test_frames_in_flight_on_independent_work_sets():
+    """rtx_opts.work_set: frames queued on different streams through different work sets overlap on the GPU and give the
+    canvas a frame gives alone; sets are checked, and a frame cut into lanes or carrying per-launch events must use set 0."""
+    import torch
+
+    world, cam, keep = rta.composite_scene(_teapot_text(), 640, 360)
+    scene = rta.Scene(world)
+    fcam = rta.flatten_camera(cam)
+    want, _ = scene.render(fcam)
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    rgb = [torch.full((360, 640, 3), float(k + 2), dtype=torch.float32, device="cuda") for k in range(3)]
+    for rounds in range(4):  # twelve frames, three in flight
+        for k in range(3):
+            scene.render_device(fcam, rgb[k].data_ptr(), None, stream=streams[k].cuda_stream, work_set=k)
+    torch.cuda.synchronize()
+    for k in range(3):
+        assert rgb[k].cpu().numpy().tobytes() == want.tobytes(), "work set %d" % k
+    with pytest.raises(rta.RtxError, match="work_set"):
+        scene.render_device(fcam, rgb[0].data_ptr(), None, stream=streams[0].cuda_stream, work_set=3)
+    with pytest.raises(rta.RtxError, match="work_set"):
+        scene.render_device(fcam, rgb[0].data_ptr(), None, stream=streams[0].cuda_stream, work_set=1, lanes=2)
+    with pytest.raises(rta.RtxError, match="work_set"):
+        scene.render_device(fcam, rgb[0].data_ptr(), None, stream=streams[0].cuda_stream, work_set=2, profile=True)
+    scene.close()
+
+
 def test_device_canvas_and_u8_quantisation():
     import torch
 
