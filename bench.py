@@ -282,6 +282,9 @@ def main():
     tstream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(tstream)
     stream = tstream.cuda_stream
+    # the copy stream of the D2H leg, created next to the render stream: the runtime deals streams to its few hardware queues in
+    # creation order, and a copy stream that lands on the render stream's queue serialises with it (2.7 instead of 1.8 ms per frame)
+    copy_stream = torch.cuda.Stream(device=dev)
 
     obj_text = rta.teapot_obj_text(1)
     world, cam, keep = rta.composite_scene(obj_text, WIDTH, HEIGHT)
@@ -432,7 +435,6 @@ def main():
         args.no_cpu = args.no_configs = True
     if n == 1 and rank == 0 and not args.headline_only:
         # --- the same frame loop with the u8 canvas landing in pinned host memory (SURVEY §8d's frame time) ---
-        copy_stream = torch.cuda.Stream(device=dev)
         host8 = [torch.empty(rgb8[0].shape, dtype=torch.uint8, pin_memory=True) for _ in range(2)]
         rendered = [torch.cuda.Event() for _ in range(2)]
         copied = [torch.cuda.Event() for _ in range(2)]
