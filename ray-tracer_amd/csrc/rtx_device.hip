@@ -183,6 +183,9 @@ struct Totals {
 template <bool ON>
 struct Tally {
     uint32_t bvh_box = 0, bvh_tri = 0, gate = 0, shape[6] = {0, 0, 0, 0, 0, 0};
+#ifdef RTX_EXP_TIMELINE
+    uint32_t box_turns = 0, tri_turns = 0;  // not counted by the statistics kernels
+#endif
 #if defined(RTX_EXP_SLOTS) && defined(__HIP_DEVICE_COMPILE__)
     // Experiment (tools/build_variant.sh slots -DRTX_EXP_SLOTS): count the lane SLOTS each loop iteration
     // occupies (64 per wave iteration) instead of the lanes that test; events / slots = lane utilisation.
@@ -203,8 +206,24 @@ struct Tally {
 };
 template <>
 struct Tally<false> {
+#ifdef RTX_EXP_TIMELINE
+    // loop turns of the wave (not lane events): the first active lane of each turn counts it
+    uint32_t box_turns = 0, tri_turns = 0;
+#ifdef __HIP_DEVICE_COMPILE__
+    __device__ __forceinline__ void turn(uint32_t& c) {
+        const unsigned long long m = __ballot(1);
+        if (__lane_id() == (uint32_t)(__ffsll((long long)m) - 1)) c += 1u;
+    }
+    __device__ __forceinline__ void box() { turn(box_turns); }
+    __device__ __forceinline__ void tri() { turn(tri_turns); }
+#else
+    void box() {}
+    void tri() {}
+#endif
+#else
     RTX_HD void box() {}
     RTX_HD void tri() {}
+#endif
     __device__ __forceinline__ void gates(bool) {}
     __device__ __forceinline__ void shapes(uint32_t, bool) {}
 };
@@ -1068,6 +1087,25 @@ int run_levels(rtx_scene* s, WorkSet& w, P& p, uint32_t pixels, uint32_t level0_
         hipLaunchKernelGGL(k_accumulate, dim3(1), dim3(64), 0, st, p.counters, w.d_totals, level0_items ? pixels : 0u, last_level,
                            first ? 1u : 0u);
     HIP_TRY(hipGetLastError());
+#ifdef RTX_EXP_DUMP_SHARDS
+    if (getenv("RTX_DUMP_SHARDS")) {  // experiment: how evenly a level's rays are spread over the shards
+        HIP_TRY(hipStreamSynchronize(st));
+        static Counters hc;
+        HIP_TRY(hipMemcpy(&hc, p.counters, sizeof(Counters), hipMemcpyDeviceToHost));
+        for (uint32_t l = 0; l < last_level; ++l) {
+            uint64_t mn = ~0ull, mx = 0, sum = 0, cmn = ~0ull, cmx = 0, csum = 0;
+            for (uint32_t k = 0; k < kShards; ++k) {
+                const uint64_t a = (uint32_t)hc.shard[k].alloc[l], r = (uint32_t)hc.shard[k].refr[l], n = a + r;
+                const uint64_t c = (a + 63) / 64 + (r + 63) / 64;
+                mn = n < mn ? n : mn; mx = n > mx ? n : mx; sum += n;
+                cmn = c < cmn ? c : cmn; cmx = c > cmx ? c : cmx; csum += c;
+            }
+            fprintf(stderr, "level %u in: rays per shard min %llu mean %.0f max %llu (max/mean %.3f); chunks min %llu mean %.1f max %llu\n", l + 1,
+                    (unsigned long long)mn, (double)sum / kShards, (unsigned long long)mx, (double)mx * kShards / (double)sum,
+                    (unsigned long long)cmn, (double)csum / kShards, (unsigned long long)cmx);
+        }
+    }
+#endif
     w.counter_set ^= 1u;
     w.counters_dirty = false;
     return RTX_OK;
@@ -1322,6 +1360,19 @@ extern "C" __attribute__((visibility("default"))) int rtx_diag_read(unsigned lon
     if (reset) {
         unsigned long long z[16] = {0};
         HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_diag), z, sizeof z));
+    }
+    return 0;
+}
+#endif
+
+#ifdef RTX_EXP_TIMELINE
+extern "C" __attribute__((visibility("default"))) int rtx_exp_timeline_read(unsigned long long* out, int reset) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(f32::g_timeline), sizeof(unsigned long long) * kLevels * 8192 * 12));
+    if (reset) {
+        void* ptr = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(f32::g_timeline)));
+        HIP_TRY(hipMemset(ptr, 0, sizeof(unsigned long long) * kLevels * 8192 * 12));
     }
     return 0;
 }
