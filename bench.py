@@ -484,7 +484,8 @@ def main():
                 "frac_of_fp64_vector_peak": trace_shade_flops(stats) / (ms64 * 1e-3) / 1e12 / 78.6,
                 "pixels_within_1_lsb_of_f32": float((diff <= 1).mean()), "pixels_identical_to_f32": float((diff == 0).mean()),
                 "note": "rtx_opts.real = RTX_REAL_F64: every computed quantity, the ray queues and the ray-tree nodes in double, scene "
-                        "records f32; plainest kernel variants (tables in global memory, four-lane arithmetic), 2 waves per SIMD; flops are "
+                        "records f32; canonical-w variants with the hit records in LDS at 3 waves per SIMD where the scene allows them "
+                        "(this frame), else the plainest variants at 2; flops are "
                         "the f32 frame's event counts priced with the same table, over the whole frame time (not one kernel)",
             }
         except rta.RtxError as e:  # e.g. not enough memory for the double queues next to the f32 ones
