@@ -22,9 +22,11 @@ Time is the max over ranks between two barrier+synchronize pairs; all gathers ar
 With fewer visible GPUs than ranks the run is a REHEARSAL (all ranks on GPU 0, gloo): it checks the N > 1
 code path (what rank 0 received equals the whole-frame render) and says "rehearsal": true — not a measurement.
 
-N = 1 keeps two frames in flight by default (--frames-in-flight): frame k runs through work set k % 2 of the scene
-(rtx_opts.work_set: its own ray queues, nodes and counters) on stream k % 2 into canvases of its own, so the deep levels of one
-frame — few rays, latency-bound, 58-62 % of the VALU issue slots used — share the chip with the next frame's level 0.  `value` and
+Frames in flight (--frames-in-flight F; default 2 at N = 1, 3 at N > 1): frame k runs through work set k % F of the scene
+(rtx_opts.work_set: its own ray queues, nodes and counters) on stream k % F into canvases (and, at N > 1, exchange buffers) of its
+own, so the deep levels of one frame — few rays, latency-bound, 58-62 % of the VALU issue slots used — share the chip with the next
+frame's level 0.  A rank's share of a split frame fills ever less of its chip per launch, so the ranks of an N > 1 run keep three
+in flight (tools/strip_share.py: rank 0's eighth of the frame takes 0.47 / 0.28 / 0.23 ms per frame with 1 / 2 / 3).  `value` and
 `ms_per_step` are that loop's throughput; `config.frame_ms_one_at_a_time` is the same frame with nothing else in flight.  Timed
 steps that carry per-launch HIP events run alone (the other slot is drained first and waits), so `roofline` prices a kernel by
 itself; `--headline-only` (the command profiles/ traces) keeps one frame in flight throughout.
@@ -226,9 +228,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--frames-in-flight", type=int, default=2,
-                    help="N = 1: frame k runs through work set k %% F of the scene (rtx_opts.work_set) on stream k %% F, so the deep, "
-                         "latency-bound levels of one frame share the chip with the next frame's level 0; 1 = one frame at a time")
+    ap.add_argument("--frames-in-flight", type=int, default=0,
+                    help="frame k runs through work set k %% F of the scene (rtx_opts.work_set) on stream k %% F, so the deep, "
+                         "latency-bound levels of one frame share the chip with the next frame's level 0; 1 = one frame at a time; "
+                         "default: 2 at N = 1, 3 at N > 1 (a rank's share of a split frame fills less of its chip per launch)")
     ap.add_argument("--lanes", type=int, default=1, help="rtx_opts.lanes for the timed frames (2 is an experiment: see rtx.h)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline legs")
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configs")
@@ -293,22 +296,25 @@ def main():
     split = n > 1 and not args.whole_frames
     strips = (STRIP_ROWS, n, rank) if split else None
     max_rows = tiling.slot_rows(HEIGHT, STRIP_ROWS, n) if split else HEIGHT  # equal-size gather slots
-    rgb = torch.zeros((max_rows, WIDTH, 3), dtype=torch.float32, device=dev)
-    # Two u8 canvas sets: while set b travels (to rank 0, or to the host) the next step renders into set 1 - b.
-    rgb8 = [torch.zeros((1, max_rows, WIDTH, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
+    # F frames in flight, each on a stream, canvases, an exchange buffer set and a work set (rtx_opts.work_set) of its own; slot 0
+    # is the stream above.  N > 1 defaults to three: a rank's share of a split frame fills ever less of its chip per launch
+    # (tools/strip_share.py: rank 0's eighth of the frame takes 0.47 / 0.28 / 0.23 ms with 1 / 2 / 3 in flight).
+    F = args.frames_in_flight if args.frames_in_flight else (2 if n == 1 else 3)
+    F = max(1, min(3, F))
+    n_sets = max(F, 2)  # the D2H leg and the scaling extras alternate between two canvases whatever F is
+    slot_streams = [tstream] + [torch.cuda.Stream(device=dev) for _ in range(F - 1)]
+    slot_rgb = [torch.zeros((max_rows, WIDTH, 3), dtype=torch.float32, device=dev) for _ in range(F)]
+    rgb = slot_rgb[0]
+    # u8 canvas sets: while set b travels (to rank 0, or to the host) later steps render into the others.
+    rgb8 = [torch.zeros((1, max_rows, WIDTH, 3), dtype=torch.uint8, device=dev) for _ in range(n_sets)]
+    slot_done = [torch.cuda.Event() for _ in range(F)]
     exchange = whole_slots = None
     if split:
-        exchange = tiling.StripExchange(HEIGHT, WIDTH, STRIP_ROWS, frames=1, device=dev)
+        exchange = tiling.StripExchange(HEIGHT, WIDTH, STRIP_ROWS, frames=1, device=dev, sets=n_sets)
     elif n > 1:
         gdev = torch.device("cpu") if rehearse else dev
-        whole_slots = [[torch.zeros(rgb8[0].shape, dtype=torch.uint8, device=gdev) for _ in range(n)] for _ in range(2)] if rank == 0 else None
+        whole_slots = [[torch.zeros(rgb8[0].shape, dtype=torch.uint8, device=gdev) for _ in range(n)] for _ in range(n_sets)] if rank == 0 else None
     pending = {}
-    # N = 1: F frames in flight, each on a stream, canvases and a work set of its own (slot 0 is the stream and the canvases above)
-    F = max(1, min(3, args.frames_in_flight)) if n == 1 else 1
-    slot_streams = [tstream] + [torch.cuda.Stream(device=dev) for _ in range(F - 1)]
-    slot_rgb = [rgb] + [torch.zeros_like(rgb) for _ in range(F - 1)]
-    slot_rgb8 = [rgb8[0]] + [torch.zeros_like(rgb8[0]) for _ in range(F - 1)]
-    slot_done = [torch.cuda.Event() for _ in range(F)]
 
     def finish(b):
         if exchange is not None:
@@ -319,33 +325,30 @@ def main():
                 work.wait()
 
     def frame(k, profile):
-        if F > 1:
-            # A frame that carries per-launch events runs alone (slot 0 waits for the others, the others wait for it): its
-            # kernels must not share the chip with another frame's if their durations are to be those of a kernel.
-            slot = 0 if profile else k % F
-            if profile:
-                for other in range(1, F):
-                    slot_streams[0].wait_event(slot_done[other])
-            scene.render_device(fcam, slot_rgb[slot].data_ptr(), slot_rgb8[slot].data_ptr(), stream=slot_streams[slot].cuda_stream,
-                                profile=profile, lanes=args.lanes, work_set=slot)
-            slot_done[slot].record(slot_streams[slot])
-            if profile:
-                for other in range(1, F):
-                    slot_streams[other].wait_event(slot_done[0])
-            return
-        b = k & 1
-        finish(b)  # set b is free again once its last gather has landed
-        scene.render_device(fcam, rgb.data_ptr(), rgb8[b].data_ptr(), stream=stream, strips=strips, compact_rows=split,
-                            profile=profile, lanes=args.lanes)
-        if exchange is not None:  # canvas exchange: every peer sends its u8 strips straight to rank 0
-            exchange.submit(b, rgb8[b])
-        elif n > 1:
-            src = rgb8[b].cpu() if rehearse else rgb8[b]
-            pending[b] = (dist.gather(src, whole_slots[b] if rank == 0 else None, dst=0, async_op=True), src)
+        # A frame that carries per-launch events runs alone (slot 0 waits for the others, the others wait for it): its
+        # kernels must not share the chip with another frame's if their durations are to be those of a kernel.
+        slot = 0 if profile else k % F
+        if profile:
+            for other in range(1, F):
+                slot_streams[0].wait_event(slot_done[other])
+        with torch.cuda.stream(slot_streams[slot]):  # the exchange's collectives and waits follow torch's current stream
+            finish(slot)  # set `slot` is free again once its last gather has landed
+            scene.render_device(fcam, slot_rgb[slot].data_ptr(), rgb8[slot].data_ptr(), stream=slot_streams[slot].cuda_stream,
+                                strips=strips, compact_rows=split, profile=profile, lanes=args.lanes, work_set=slot)
+            if exchange is not None:  # canvas exchange: every peer sends its u8 strips straight to rank 0
+                exchange.submit(slot, rgb8[slot])
+            elif n > 1:
+                src = rgb8[slot].cpu() if rehearse else rgb8[slot]
+                pending[slot] = (dist.gather(src, whole_slots[slot] if rank == 0 else None, dst=0, async_op=True), src)
+        slot_done[slot].record(slot_streams[slot])
+        if profile:
+            for other in range(1, F):
+                slot_streams[other].wait_event(slot_done[0])
 
     def fence():
-        for b in (0, 1):
-            finish(b)
+        for b in range(F):
+            with torch.cuda.stream(slot_streams[b]):
+                finish(b)
         if n > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -373,14 +376,14 @@ def main():
             scene.render_device(fcam, rgb.data_ptr(), rgb8[0].data_ptr(), stream=stream, lanes=args.lanes)
         torch.cuda.synchronize()
         frame_ms_alone = (time.perf_counter() - t_a) / 20 * 1e3
-        assert all(torch.equal(slot_rgb8[0], x) for x in slot_rgb8[1:]), "the canvases of the frame slots differ"
+        assert all(torch.equal(rgb8[0], x) for x in rgb8[1:F]), "the canvases of the frame slots differ"
 
     if rehearse and n > 1 and rank == 0:  # what arrived must be the whole-frame render, byte for byte
         whole = rta.to_ppm_bytes(scene.render(fcam)[0])[None]
         if split:
             assert np.array_equal(exchange.full.numpy(), whole), "re-interleaved strips differ from the whole-frame render"
         else:
-            for b in range(2):
+            for b in range(F):
                 for r in range(n):
                     assert np.array_equal(whole_slots[b][r].numpy(), whole), "canvas set %d of rank %d differs" % (b, r)
         print("rehearsal (%s): the canvases gathered from %d ranks equal the whole-frame render" % (
@@ -531,9 +534,9 @@ def main():
                 "parallelism": ("1 GPU, %d frames in flight (frame k on work set and stream k %% %d: a frame's deep, latency-bound levels share "
                                 "the chip with the next frame's level 0; frames with per-launch events run alone)" % (F, F) if F > 1 else "1 GPU") if n == 1 else (
                     "%d ranks x 16-row strips of every frame, RCCL gather + re-interleave of the u8 strips on rank 0, "
-                    "overlapped with the next step" % n if split
+                    "overlapped with the next steps; %d frames in flight per rank (work set, stream and exchange buffers k %% %d)" % (n, F, F) if split
                     else "%d ranks x whole frames, one RCCL gather of the u8 canvases per step on rank 0, overlapped "
-                         "with the next step" % n),
+                         "with the next steps; %d frames in flight per rank" % (n, F)),
             },
             "roofline": {
                 "bound": "valu", "kernel": "k_trace_shade",

@@ -68,14 +68,18 @@ def gather_canvas(local, height, strip_rows, rows_quirk=True, group=None, out=No
 class StripExchange:
     """The canvas exchange of a split frame loop: every rank hands over its compact u8 strips
     [frames, slot_rows, W, C]; rank 0 gathers them (one collective per step, asynchronous: RCCL
-    runs it on its own stream) and puts every row back in place in `full` [frames, H, W, C].
+    runs it on its own stream) and puts every row back in place in `fulls[b]` [frames, H, W, C]
+    (`full` is the set finished last).
 
-    Double-buffered: set b may travel while the next step renders into set 1 - b; `finish(b)`
-    must be called before set b's source buffer is written again.  With the gloo backend
-    (CPU tests, single-GPU rehearsals) device tensors are staged through host memory.
+    `sets` buffer sets (default 2): set b may travel while later steps render into the other sets; `finish(b)`
+    must be called before set b's source buffer is written again.  submit / finish act on torch's CURRENT
+    stream: a loop that keeps several frames in flight calls them inside `torch.cuda.stream(...)` of the frame's
+    own stream; the sets share nothing but the process group, whose collectives run in the order they are issued
+    (the same on every rank).  With the gloo backend (CPU tests, single-GPU rehearsals) device tensors are staged
+    through host memory.
     """
 
-    def __init__(self, height, width, strip_rows, frames=1, channels=3, rows_quirk=True, device="cpu", group=None):
+    def __init__(self, height, width, strip_rows, frames=1, channels=3, rows_quirk=True, device="cpu", group=None, sets=2):
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.group = group
@@ -85,22 +89,25 @@ class StripExchange:
         self.device = torch.device(device)
         self.staged = dist.get_backend(group) == "gloo" and self.device.type != "cpu"
         self.gather_device = torch.device("cpu") if self.staged else self.device
+        self.sets = sets
         shape = (frames, self.slot_rows, width, channels)
-        self.slots = self.full = None
+        self.slots = self.fulls = self.full = None
         if self.rank == 0:
-            self.slots = [[torch.zeros(shape, dtype=torch.uint8, device=self.gather_device) for _ in range(self.world)] for _ in range(2)]
-            self.full = torch.zeros((frames, height, width, channels), dtype=torch.uint8, device=self.gather_device)
+            self.slots = [[torch.zeros(shape, dtype=torch.uint8, device=self.gather_device) for _ in range(self.world)] for _ in range(sets)]
+            self.fulls = [torch.zeros((frames, height, width, channels), dtype=torch.uint8, device=self.gather_device) for _ in range(sets)]
+            self.full = self.fulls[0]
         self.pending = {}
 
     def submit(self, b, local):
         """Start the gather of canvas set b (a [frames, slot_rows, W, C] u8 tensor on `device`)."""
+        assert 0 <= b < self.sets, "set %d of %d" % (b, self.sets)
         assert b not in self.pending, "finish(%d) first" % b
         src = local.cpu() if self.staged else local
         work = dist.gather(src, self.slots[b] if self.rank == 0 else None, dst=0, group=self.group, async_op=True)
         self.pending[b] = (work, src)  # src: keeps a staged host copy alive until the gather has landed
 
     def finish(self, b):
-        """Wait for set b's gather; on rank 0 re-interleave the strips into `full`."""
+        """Wait for set b's gather; on rank 0 re-interleave the strips into `fulls[b]`."""
         work, _src = self.pending.pop(b, (None, None))
         if work is None:
             return
@@ -109,7 +116,8 @@ class StripExchange:
             for r in range(self.world):
                 idx = row_index(self.height, self.strip_rows, self.world, r, self.rows_quirk, self.gather_device)
                 if idx.numel():
-                    self.full.index_copy_(1, idx, self.slots[b][r][:, : idx.numel()])
+                    self.fulls[b].index_copy_(1, idx, self.slots[b][r][:, : idx.numel()])
+            self.full = self.fulls[b]
 
     def drain(self):
         for b in list(self.pending):

@@ -74,7 +74,7 @@ def test_two_ranks_gather_reassembles_the_canvas(height, strip):
     assert _run(_worker, 2, height, 48, strip) == 1
 
 
-def _render_worker(rank, world, port, name, width, height, strip, steps, ok):
+def _render_worker(rank, world, port, name, width, height, strip, steps, sets, ok):
     """bench.py's split-frame loop (tiling.StripExchange) with a real renderer behind it: the oracle
     renders the frame (tests may use it; there is no GPU here), each rank keeps only its strips'
     rows, and after `steps` double-buffered exchanges rank 0 must hold the whole frame's PPM bytes."""
@@ -90,11 +90,11 @@ def _render_worker(rank, world, port, name, width, height, strip, steps, ok):
         whole = o.to_ppm_bytes(canvas)
         rows = tiling.rows_of_rank(height, strip, world, rank)
         assert len(rows) == rta.rows_for(s.camera, strips=(strip, world, rank))
-        ex = tiling.StripExchange(height, width, strip, frames=1)
+        ex = tiling.StripExchange(height, width, strip, frames=1, sets=sets)
         assert ex.local_rows == len(rows)
-        local = [torch.zeros((1, ex.slot_rows, width, 3), dtype=torch.uint8) for _ in range(2)]
+        local = [torch.zeros((1, ex.slot_rows, width, 3), dtype=torch.uint8) for _ in range(sets)]
         for k in range(steps):
-            b = k & 1
+            b = k % sets  # bench.py: frame k travels through buffer set k % F
             ex.finish(b)
             local[b].fill_(k)                                   # leftovers of an earlier step must not survive
             local[b][0, : len(rows)] = torch.from_numpy(whole[rows])  # "render" this rank's strips, compact
@@ -102,14 +102,15 @@ def _render_worker(rank, world, port, name, width, height, strip, steps, ok):
         ex.drain()
         dist.barrier()
         if rank == 0:
-            ok.value = int(np.array_equal(ex.full[0].numpy(), whole) and whole.any())
+            ok.value = int(all(np.array_equal(f[0].numpy(), whole) for f in ex.fulls) and ex.full is ex.fulls[(steps - 1) % sets] and whole.any())
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,name,width,height,strip", [(2, "glass_spheres", 64, 48, 16), (3, "sphere_world", 50, 70, 8)])
-def test_strip_exchange_of_rendered_frames(world, name, width, height, strip):
-    assert _run(_render_worker, world, name, width, height, strip, 5) == 1
+@pytest.mark.parametrize("world,name,width,height,strip,sets", [(2, "glass_spheres", 64, 48, 16, 2), (3, "sphere_world", 50, 70, 8, 2),
+                                                                (2, "glass_spheres", 64, 48, 16, 3)])
+def test_strip_exchange_of_rendered_frames(world, name, width, height, strip, sets):
+    assert _run(_render_worker, world, name, width, height, strip, 7, sets) == 1
 
 
 @pytest.mark.parametrize("height,gpus,chunks", [(1080, 2, 1), (2160, 8, 1), (2160, 8, 4), (70, 3, 2), (16, 4, 3), (500, 1, 1)])
