@@ -76,6 +76,7 @@ constexpr uint32_t kLinkSlotBit = 1u << 30;    // 0: reflected slot, 1: refracte
 constexpr uint32_t kLinkSchlickBit = 1u << 31; // in a node's link: the node combines with Schlick reflectance
 constexpr int kMaxDepth = 5;                   // src/world.zig:20
 constexpr int kLevels = kMaxDepth + 1;
+constexpr uint32_t kMaxCull = 16;  // Params.cull: camera-ray tile culling entries per frame
 
 // The traversal code of the triangle BVH (and the tuple math under it) also compiles for the
 // host: rtx_bvh_selftest runs it on the CPU against brute force, so the culling logic is
@@ -426,6 +427,11 @@ struct rtx_scene {
     std::vector<rtx_node> h_nodes;  // the gates as uploaded (BVH links included): refit re-uploads them with new boxes
     bool host_trees = false;        // some tree came from the host builder (such a scene cannot be refitted)
     TwinTable h_twins{};            // twin shapes resolved per ray (n_classes == 0: none)
+    struct CullBox {                // world-space box of a gate or of a linearly tested shape (Params.cull)
+        uint32_t id;                // index | kind << 8 (kind 1: gate, index into the walkable list)
+        double lo[3], hi[3];
+    };
+    std::vector<CullBox> cull_boxes;
     TwinTable* d_twins = nullptr;
     bool broken = false;            // a refit failed after it had started to overwrite device records: every render call fails
     rtx_material* d_materials = nullptr;
@@ -926,6 +932,173 @@ std::vector<HitRec> build_hitrecs(const std::vector<rtx_shape>& shapes) {
     return out;
 }
 
+// Inverse of a row-major 4x4 in double (Gauss-Jordan with partial pivoting); false if singular.
+bool invert4(const float* m, double* out) {
+    double a[4][8];
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) {
+            a[r][c] = m[r * 4 + c];
+            a[r][4 + c] = r == c ? 1.0 : 0.0;
+        }
+    for (int c = 0; c < 4; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < 4; ++r)
+            if (std::fabs(a[r][c]) > std::fabs(a[piv][c])) piv = r;
+        if (!(std::fabs(a[piv][c]) > 1e-300) || !std::isfinite(a[piv][c])) return false;
+        for (int k = 0; k < 8; ++k) std::swap(a[c][k], a[piv][k]);
+        const double inv = 1.0 / a[c][c];
+        for (int k = 0; k < 8; ++k) a[c][k] *= inv;
+        for (int r = 0; r < 4; ++r) {
+            if (r == c) continue;
+            const double f = a[r][c];
+            for (int k = 0; k < 8; ++k) a[r][k] -= f * a[c][k];
+        }
+    }
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) out[r * 4 + c] = a[r][4 + c];
+    return true;
+}
+
+// World-space boxes for the camera-ray tile culling (Params.cull): the gates of the walkable list that have a box, then
+// the linearly tested shapes with a finite extent, indices below 32 only, at most kMaxCull.  Conservative by
+// construction: a gate's box is the very box its test uses; a shape's is the box of its object-space extent's eight
+// corners under the inverse of its (f32) `inverse`, padded.
+std::vector<rtx_scene::CullBox> cull_boxes(const std::vector<rtx_shape>& shapes, const std::vector<rtx_node>& walk) {
+    std::vector<rtx_scene::CullBox> out;
+    for (uint32_t n = 0; n < walk.size() && n < 32u && out.size() < kMaxCull; ++n) {
+        if (!walk[n].has_bounds) continue;
+        rtx_scene::CullBox b;
+        b.id = n | 0x100u;
+        bool finite = true;
+        for (int k = 0; k < 3; ++k) {
+            b.lo[k] = walk[n].bounds_min[k];
+            b.hi[k] = walk[n].bounds_max[k];
+            finite = finite && std::isfinite(b.lo[k]) && std::isfinite(b.hi[k]) && b.lo[k] <= b.hi[k];
+        }
+        if (finite) out.push_back(b);
+    }
+    std::vector<bool> linear(shapes.size() < 32u ? shapes.size() : 32u, false);
+    for (const rtx_node& nd : walk)
+        for (uint32_t k = nd.first_shape; k < nd.first_shape + nd.reserved[1] && k < linear.size(); ++k) linear[k] = true;
+    for (uint32_t i = 0; i < linear.size() && out.size() < kMaxCull; ++i) {
+        const rtx_shape& sh = shapes[i];
+        if (!linear[i] || (sh.flags & kShapeTwin)) continue;  // a twin's test also records that the ray reached it
+        double lo[3] = {-1.0, -1.0, -1.0}, hi[3] = {1.0, 1.0, 1.0};
+        double pts[8][3];
+        int n_pts = 8;
+        switch (sh.type) {
+        case RTX_SPHERE:
+        case RTX_CUBE: break;
+        case RTX_CYLINDER: {
+            if (!std::isfinite(sh.minimum) || !std::isfinite(sh.maximum) || !(sh.minimum <= sh.maximum)) continue;
+            lo[1] = sh.minimum;
+            hi[1] = sh.maximum;
+            break;
+        }
+        // no cones: a ray parallel to one of the cone's halves gets its single root WITHOUT the check against minimum /
+        // maximum (src/cone.zig:35-39), so even a truncated cone can be hit anywhere on the infinite one
+        case RTX_TRIANGLE: n_pts = 3; break;
+        default: continue;  // planes have no extent; cones: see above
+        }
+        if (sh.type == RTX_TRIANGLE) {
+            for (int k = 0; k < 3; ++k) {
+                pts[0][k] = sh.p0[k];
+                pts[1][k] = (double)sh.p0[k] + sh.e0[k];
+                pts[2][k] = (double)sh.p0[k] + sh.e1[k];
+            }
+        } else {
+            for (int c = 0; c < 8; ++c)
+                for (int k = 0; k < 3; ++k) pts[c][k] = ((c >> k) & 1) ? hi[k] : lo[k];
+        }
+        double fwd[16];
+        if (!invert4(sh.inverse, fwd)) continue;
+        rtx_scene::CullBox b;
+        b.id = i;
+        for (int k = 0; k < 3; ++k) {
+            b.lo[k] = INFINITY;
+            b.hi[k] = -INFINITY;
+        }
+        bool finite = true;
+        for (int c = 0; c < n_pts; ++c) {
+            const double w = fwd[12] * pts[c][0] + fwd[13] * pts[c][1] + fwd[14] * pts[c][2] + fwd[15];
+            for (int k = 0; k < 3; ++k) {
+                const double x = (fwd[k * 4] * pts[c][0] + fwd[k * 4 + 1] * pts[c][1] + fwd[k * 4 + 2] * pts[c][2] + fwd[k * 4 + 3]) / w;
+                finite = finite && std::isfinite(x);
+                b.lo[k] = std::fmin(b.lo[k], x);
+                b.hi[k] = std::fmax(b.hi[k], x);
+            }
+        }
+        if (!finite) continue;
+        for (int k = 0; k < 3; ++k) {  // the shape's own f32 arithmetic reaches a little beyond its exact extent
+            const double pad = 1e-4 * (b.hi[k] - b.lo[k]) + 1e-5 * std::fmax(std::fabs(b.lo[k]), std::fabs(b.hi[k])) + 1e-9;
+            b.lo[k] -= pad;
+            b.hi[k] += pad;
+        }
+        out.push_back(b);
+    }
+    return out;
+}
+
+// Params.cull for one frame: every box of the scene's list projected through the camera.  A camera ray's line meets a
+// box only if its pixel lies in the hull of the box's projected corners — provided the box lies wholly on one side of
+// the plane through the eye parallel to the image (either side: the line reaches behind the eye, and negative roots
+// feed n1); a box that straddles that plane gets no entry.  Two pixels of margin cover the rounding of rayForPixel
+// and of the tests themselves.  RTX_NO_TILE_CULL=1 switches it off (A/B; same canvas).
+template <class P>
+void fill_cull(const rtx_scene* s, const rtx_camera* cam, const RowPlan& plan, bool gates_too, P& p) {
+    p.n_cull = 0;
+    if (getenv("RTX_NO_TILE_CULL")) return;
+    const uint32_t W = cam->horizontal_size, H = cam->vertical_size;
+    if (W > 65000u || H > 65000u) return;
+    if (plan.strip_count > 1 && plan.strip_rows % 8u != 0u) return;  // a tile's eight rows must be consecutive image rows
+    double view[16];  // world -> camera
+    if (!invert4(cam->inverse_transform, view)) return;
+    const double ps = cam->pixel_size, hw = cam->half_width, hh = cam->half_height;
+    if (!(ps > 0.0) || !std::isfinite(ps)) return;
+    for (const rtx_scene::CullBox& b : s->cull_boxes) {
+        if ((b.id & 0x100u) && !gates_too) continue;
+        double x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
+        int front = 0, back = 0;
+        bool ok = true;
+        for (int c = 0; c < 8 && ok; ++c) {
+            const double q[3] = {(c & 1) ? b.hi[0] : b.lo[0], (c & 2) ? b.hi[1] : b.lo[1], (c & 4) ? b.hi[2] : b.lo[2]};
+            double v[4];
+            for (int r = 0; r < 4; ++r) v[r] = view[r * 4] * q[0] + view[r * 4 + 1] * q[1] + view[r * 4 + 2] * q[2] + view[r * 4 + 3];
+            const double x = v[0] / v[3], y = v[1] / v[3], z = v[2] / v[3];
+            const double reach = std::fabs(x) + std::fabs(y) + std::fabs(z);
+            if (!std::isfinite(reach) || !(std::fabs(z) > 1e-6 * reach)) {
+                ok = false;
+                break;
+            }
+            (z < 0.0 ? front : back) += 1;
+            const double px = (hw + x / z) / ps - 0.5, py = (hh + y / z) / ps - 0.5;  // the pixel whose ray's line passes through the corner
+            x0 = std::fmin(x0, px);
+            x1 = std::fmax(x1, px);
+            y0 = std::fmin(y0, py);
+            y1 = std::fmax(y1, py);
+        }
+        if (!ok || (front != 0 && back != 0)) continue;
+        if (!std::isfinite(x0) || !std::isfinite(x1) || !std::isfinite(y0) || !std::isfinite(y1)) continue;
+        const double m = 2.0;
+        double fx0 = std::floor(x0 - m), fx1 = std::ceil(x1 + m), fy0 = std::floor(y0 - m), fy1 = std::ceil(y1 + m);
+        if (fx0 <= 0.0 && fy0 <= 0.0 && fx1 >= W - 1.0 && fy1 >= H - 1.0) continue;  // covers the frame: nothing to gain
+        uint32_t r[4];
+        if (fx1 < 0.0 || fy1 < 0.0 || fx0 > W - 1.0 || fy0 > H - 1.0) {
+            r[0] = 65535u, r[1] = 0u, r[2] = 65535u, r[3] = 0u;  // off the frame: no tile touches it
+        } else {
+            r[0] = (uint32_t)std::fmax(fx0, 0.0);
+            r[1] = (uint32_t)std::fmin(fx1, 65535.0);
+            r[2] = (uint32_t)std::fmax(fy0, 0.0);
+            r[3] = (uint32_t)std::fmin(fy1, 65535.0);
+        }
+        uint32_t* e = p.cull[p.n_cull++];
+        e[0] = r[0] | (r[1] << 16);
+        e[1] = r[2] | (r[3] << 16);
+        e[2] = b.id;
+        if (p.n_cull == kMaxCull) break;
+    }
+}
+
 int check_camera(const rtx_camera* cam) {
     if (!cam) return fail(RTX_E_INVALID, "camera is NULL");
     if (cam->horizontal_size == 0 || cam->vertical_size == 0) return fail(RTX_E_INVALID, "empty canvas");
@@ -1249,6 +1422,8 @@ int render_impl_t(rtx_scene* s, const rtx_camera* cam, const rtx_opts* opts, flo
     p.strip_index = plan.strip_index;
     p.compact_rows = compact ? 1u : 0u;
     p.canvas = d_rgb;
+    // camera-ray tile culling: the plain walk only (a twin's test records that the ray reached it; the book walk keeps to itself)
+    if (!p.book && !p.twins) fill_cull(s, cam, plan, !(opts && opts->no_bvh), p);
 
     if (!fixed) HIP_TRY(hipEventRecord(s->ws[set0].ev_begin, st));
     // Canvas starts black (canvas.zig:23-25); rows never rendered stay black.  Every rendered
@@ -1539,6 +1714,7 @@ int rtx_scene_create(const rtx_scene_desc* desc, int device, rtx_scene** out) {
     {
         const std::vector<rtx_node> walk = walkable_nodes(nodes);
         s->n_nodes_walk = (uint32_t)walk.size();
+        s->cull_boxes = cull_boxes(shapes, walk);
         HIP_TRY_S(upload((void**)&s->d_nodes, walk.data(), sizeof(rtx_node) * walk.size()));
     }
     HIP_TRY_S(upload((void**)&s->d_nodes_linear, linear.data(), sizeof(rtx_node) * linear.size()));
@@ -1693,6 +1869,7 @@ int rtx_scene_refit(rtx_scene* s, const rtx_scene_desc* desc) {
     }
     {
         const std::vector<rtx_node> walk = walkable_nodes(s->h_nodes);  // boxes change, the structure (and so the count) does not
+        s->cull_boxes = cull_boxes(shapes, walk);
         HIP_TRY(hipMemcpy(s->d_nodes, walk.data(), sizeof(rtx_node) * walk.size(), hipMemcpyHostToDevice));
     }
     {

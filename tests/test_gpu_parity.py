@@ -7,6 +7,7 @@ tests assert that stronger property, with the north-star bar as the fallback mes
 """
 import ctypes as C
 import importlib
+import os
 
 import numpy as np
 import pytest
@@ -1186,3 +1187,95 @@ def test_f64_with_the_book_walk_is_rejected():
     b, _ = scene.render(s.camera, book=True)
     assert a.any() and b.any()
     scene.close()
+
+
+# ---------------------------------------------------------------------------------------- camera-ray tile culling
+def _render_with_and_without_tile_cull(scene, cam, **kw):
+    """(canvas with the culling on, its stats, canvas with RTX_NO_TILE_CULL=1, its stats); the switch is read per frame."""
+    os.environ.pop("RTX_NO_TILE_CULL", None)
+    on, st_on = scene.render(cam, **kw)
+    os.environ["RTX_NO_TILE_CULL"] = "1"
+    try:
+        off, st_off = scene.render(cam, **kw)
+    finally:
+        os.environ.pop("RTX_NO_TILE_CULL", None)
+    return on, st_on, off, st_off
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,w,h,culls", [("cylinder_world", 203, 117, True), ("glass_spheres", 160, 90, True), ("fresnel", 100, 70, False),
+                                           ("cube", 96, 64, True)])
+def test_tile_cull_leaves_the_canvas_alone_and_skips_tests(name, w, h, culls):
+    # Params.cull: a wave whose 8x8 tile of camera rays lies outside a shape's (or a gate's) projected box skips the test.  Same
+    # bits with the switch off, the same ray counts, fewer tests counted; sizes with partial tiles on purpose.
+    s = rta.Sample(name, w, h)
+    scene = rta.Scene(s.world)
+    on, st_on, off, st_off = _render_with_and_without_tile_cull(scene, s.camera)
+    assert on.tobytes() == off.tobytes()
+    assert (st_on.rays_primary, st_on.rays_shadow, st_on.rays_secondary) == (st_off.rays_primary, st_off.rays_shadow, st_off.rays_secondary)
+    if culls:  # fresnel's camera looks down at spheres that fill its frame: every box covers every tile
+        assert sum(st_on.shape_tests) < sum(st_off.shape_tests), "nothing was culled"
+    else:
+        assert sum(st_on.shape_tests) == sum(st_off.shape_tests)
+    # strips dealt to three ranks, compact rows (a tile's rows are image rows of one 16-row strip)
+    for k in range(3):
+        a, _, b, _ = _render_with_and_without_tile_cull(scene, s.camera, strips=(16, 3, k), compact_rows=True)
+        assert a.tobytes() == b.tobytes()
+    scene.close()
+
+
+@pytest.mark.gpu
+def test_tile_cull_on_the_mesh_composite_and_random_worlds():
+    obj = rta.teapot_obj_text(1)
+    world, cam, keep = rta.composite_scene(obj, 640, 360)
+    scene = rta.Scene(world)
+    on, st_on, off, st_off = _render_with_and_without_tile_cull(scene, cam)
+    assert on.tobytes() == off.tobytes()
+    assert st_on.gate_tests < st_off.gate_tests and st_on.shape_tests[0] < st_off.shape_tests[0]  # the teapot's gate, the spheres
+    assert st_on.bvh_box_tests == st_off.bvh_box_tests  # every ray that walks the tree still does
+    scene.close()
+    for seed in range(12):  # every shape type, nested groups with and without boxes; cameras outside and inside the shapes
+        w, keep = su.random_world(seed, n_shapes=6 + seed % 12, groups=seed % 4)
+        scene = rta.Scene(w)
+        for cam in (su.default_camera(96, 64), su.default_camera(72, 72, 1.3, frm=(0.3, 0.2, -1.5, 1), to=(0, 0.5, 2, 1))):
+            on, _, off, _ = _render_with_and_without_tile_cull(scene, cam)
+            assert on.tobytes() == off.tobytes(), "random world %d" % seed
+        scene.close()
+
+
+@pytest.mark.gpu
+def test_tile_cull_keeps_what_lies_behind_the_eye():
+    # The reference intersects LINES: a glass triangle behind the camera is crossed at negative t and stays in the container
+    # list, so it is n1 for what the ray hits in front (src/intersection.zig:92-159).  Its culling rectangle is the mirror
+    # image of its projection; tiles inside must still test it, and the canvas must be the oracle's.
+    glass = st.default_attrs()
+    glass.material.transparency = 0.9
+    glass.material.reflective = 0.3
+    glass.material.refractive_index = 1.5
+    ball = st.Sphere(glass)
+    dense = st.default_attrs()
+    dense.material.transparency = 0.8
+    dense.material.refractive_index = 2.2
+    tri = st.Triangle()
+    pts = [(C.c_float * 4)(*p) for p in ((-0.6, 1.2, -9.0, 1.0), (0.9, 1.4, -9.5, 1.0), (0.1, 2.4, -8.5, 1.0))]
+    rta.lib().rt_triangle_init(pts[0], pts[1], pts[2], C.byref(tri))
+    tri.common_attrs = dense
+    behind_ball = st.Sphere(dense)
+    behind_ball.common_attrs.transform = su.compose(su.translation(1.5, 2.5, -11), su.scaling(0.7, 0.7, 0.7))
+    floor = st.Plane(st.default_attrs())
+    floor.common_attrs.transform = su.translation(0, -1, 0)
+    w, keep = st.make_world([-4, 6, -5, 1], [1, 1, 1], spheres=[ball, behind_ball], planes=[floor], triangles=[tri])
+    cam = su.default_camera(128, 96, 1.0)  # from (0, 1.5, -7) towards the origin: the triangle and the second sphere are behind it
+    scene = rta.Scene(w)
+    on, st_on, off, st_off = _render_with_and_without_tile_cull(scene, cam)
+    assert on.tobytes() == off.tobytes()
+    assert sum(st_on.shape_tests) < sum(st_off.shape_tests)
+    ref, counts = o.render(cam, w)
+    compare(on, ref, "glass behind the eye")
+    # the triangle does change what the front sphere looks like: without it the canvas differs
+    w2, keep2 = st.make_world([-4, 6, -5, 1], [1, 1, 1], spheres=[ball, behind_ball], planes=[floor])
+    scene2 = rta.Scene(w2)
+    other, _ = scene2.render(cam)
+    assert other.tobytes() != on.tobytes()
+    scene.close()
+    scene2.close()
