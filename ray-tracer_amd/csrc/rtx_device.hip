@@ -429,6 +429,7 @@ struct rtx_scene {
     TwinTable h_twins{};            // twin shapes resolved per ray (n_classes == 0: none)
     struct CullBox {                // world-space box of a gate or of a linearly tested shape (Params.cull)
         uint32_t id;                // index | kind << 8 (kind 1: gate, index into the walkable list)
+        bool quadratic;             // a sphere or cylinder: its test's discriminant cancels (fill_cull's margin)
         double lo[3], hi[3];
     };
     std::vector<CullBox> cull_boxes;
@@ -969,6 +970,7 @@ std::vector<rtx_scene::CullBox> cull_boxes(const std::vector<rtx_shape>& shapes,
         if (!walk[n].has_bounds) continue;
         rtx_scene::CullBox b;
         b.id = n | 0x100u;
+        b.quadratic = false;
         bool finite = true;
         for (int k = 0; k < 3; ++k) {
             b.lo[k] = walk[n].bounds_min[k];
@@ -1014,6 +1016,7 @@ std::vector<rtx_scene::CullBox> cull_boxes(const std::vector<rtx_shape>& shapes,
         if (!invert4(sh.inverse, fwd)) continue;
         rtx_scene::CullBox b;
         b.id = i;
+        b.quadratic = sh.type == RTX_SPHERE || sh.type == RTX_CYLINDER;
         for (int k = 0; k < 3; ++k) {
             b.lo[k] = INFINITY;
             b.hi[k] = -INFINITY;
@@ -1079,7 +1082,18 @@ void fill_cull(const rtx_scene* s, const rtx_camera* cam, const RowPlan& plan, b
         }
         if (!ok || (front != 0 && back != 0)) continue;
         if (!std::isfinite(x0) || !std::isfinite(x1) || !std::isfinite(y0) || !std::isfinite(y1)) continue;
-        const double m = 2.0;
+        // Margin: two pixels, plus what the f32 tests of a far, small shape can add — the discriminant b^2 - 4ac of a
+        // sphere or cylinder D radii away carries an error of ~1e-7 D^2 in units of the squared radius, which moves
+        // the silhouette by ~1e-7 D^2 radii, i.e. 1e-7 (D / r) / pixel_size pixels (a 1/3-pixel sphere: 8 pixels).
+        // Ten times that; an entry whose margin would exceed 64 pixels is dropped.
+        double dist2 = 0.0, r_min = INFINITY;
+        for (int k = 0; k < 3; ++k) {
+            const double c = 0.5 * (b.lo[k] + b.hi[k]) - (double)cam->inverse_transform[k * 4 + 3] / (double)cam->inverse_transform[15];
+            dist2 += c * c;
+            r_min = std::fmin(r_min, 0.5 * (b.hi[k] - b.lo[k]));
+        }
+        const double m = 2.0 + (b.quadratic ? 1e-6 * std::sqrt(dist2) / (std::fmax(r_min, 1e-30) * ps) : 0.0);
+        if (!(m <= 64.0)) continue;
         double fx0 = std::floor(x0 - m), fx1 = std::ceil(x1 + m), fy0 = std::floor(y0 - m), fy1 = std::ceil(y1 + m);
         if (fx0 <= 0.0 && fy0 <= 0.0 && fx1 >= W - 1.0 && fy1 >= H - 1.0) continue;  // covers the frame: nothing to gain
         uint32_t r[4];

@@ -1279,3 +1279,30 @@ def test_tile_cull_keeps_what_lies_behind_the_eye():
     assert other.tobytes() != on.tobytes()
     scene.close()
     scene2.close()
+
+
+@pytest.mark.gpu
+def test_tile_cull_margin_follows_far_small_spheres():
+    # A sphere thousands of radii away: the discriminant's cancellation lets the reference's f32 test report roots for rays
+    # that pass it by many radii (pixels, at that size).  The rectangle's margin grows with distance / radius; the canvas must
+    # stay the one with every test made, and the oracle's.
+    rng = np.random.default_rng(11)
+    balls = []
+    for k in range(14):
+        a = st.default_attrs()
+        a.material.color[:] = [float(v) for v in rng.uniform(0.2, 1.0, 3)]
+        r = float(10.0 ** rng.uniform(-3.2, -1.0))
+        pos = [float(rng.uniform(-6, 6)), float(rng.uniform(-3, 5)), float(rng.uniform(5, 120))]
+        b = st.Sphere(a)
+        b.common_attrs.transform = su.compose(su.translation(*pos), su.scaling(r, r, r))
+        balls.append(b)
+    floor = st.Plane(st.default_attrs())
+    floor.common_attrs.transform = su.translation(0, -4, 0)
+    w, keep = st.make_world([-10, 10, -10, 1], [1, 1, 1], spheres=balls, planes=[floor])
+    scene = rta.Scene(w)
+    for cam in (su.default_camera(160, 120, 0.5), su.default_camera(96, 64, 1.2)):
+        on, st_on, off, st_off = _render_with_and_without_tile_cull(scene, cam)
+        assert on.tobytes() == off.tobytes()
+        ref, _ = o.render(cam, w)
+        compare(on, ref, "far small spheres")
+    scene.close()
