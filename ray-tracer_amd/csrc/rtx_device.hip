@@ -1039,6 +1039,17 @@ std::vector<rtx_scene::CullBox> cull_boxes(const std::vector<rtx_shape>& shapes,
         }
         out.push_back(b);
     }
+    // Which entries pay (measured): a cube's or a cylinder's test without a root costs ~100 instructions (six
+    // IEEE divisions; two quadratics and the caps), a sphere's ends after its discriminant (35) and a gate is decided from
+    // rcp products (45) — skipping a handful of those bought nothing on the composite, the teapot and glass_spheres, while a
+    // lone cube's frame gained 11 %.  So spheres, triangles and gates get entries only where there are many of them.
+    constexpr size_t kManyEntries = 8;
+    if (out.size() < kManyEntries) {
+        std::vector<rtx_scene::CullBox> costly;
+        for (const rtx_scene::CullBox& b : out)
+            if (!(b.id & 0x100u) && (shapes[b.id].type == RTX_CUBE || shapes[b.id].type == RTX_CYLINDER)) costly.push_back(b);
+        out.swap(costly);
+    }
     return out;
 }
 

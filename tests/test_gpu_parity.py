@@ -1203,7 +1203,7 @@ def _render_with_and_without_tile_cull(scene, cam, **kw):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,w,h,culls", [("cylinder_world", 203, 117, True), ("glass_spheres", 160, 90, True), ("fresnel", 100, 70, False),
+@pytest.mark.parametrize("name,w,h,culls", [("cylinder_world", 203, 117, True), ("glass_spheres", 160, 90, False), ("fresnel", 100, 70, False),
                                            ("cube", 96, 64, True)])
 def test_tile_cull_leaves_the_canvas_alone_and_skips_tests(name, w, h, culls):
     # Params.cull: a wave whose 8x8 tile of camera rays lies outside a shape's (or a gate's) projected box skips the test.  Same
@@ -1213,7 +1213,7 @@ def test_tile_cull_leaves_the_canvas_alone_and_skips_tests(name, w, h, culls):
     on, st_on, off, st_off = _render_with_and_without_tile_cull(scene, s.camera)
     assert on.tobytes() == off.tobytes()
     assert (st_on.rays_primary, st_on.rays_shadow, st_on.rays_secondary) == (st_off.rays_primary, st_off.rays_shadow, st_off.rays_secondary)
-    if culls:  # fresnel's camera looks down at spheres that fill its frame: every box covers every tile
+    if culls:  # a handful of spheres get no entries (their rootless test is cheap: measured, no gain); cubes, cylinders and crowds do
         assert sum(st_on.shape_tests) < sum(st_off.shape_tests), "nothing was culled"
     else:
         assert sum(st_on.shape_tests) == sum(st_off.shape_tests)
@@ -1231,8 +1231,9 @@ def test_tile_cull_on_the_mesh_composite_and_random_worlds():
     scene = rta.Scene(world)
     on, st_on, off, st_off = _render_with_and_without_tile_cull(scene, cam)
     assert on.tobytes() == off.tobytes()
-    assert st_on.gate_tests < st_off.gate_tests and st_on.shape_tests[0] < st_off.shape_tests[0]  # the teapot's gate, the spheres
-    assert st_on.bvh_box_tests == st_off.bvh_box_tests  # every ray that walks the tree still does
+    # one gate and three spheres: too few cheap tests to pay for entries, the frame runs as before
+    assert st_on.gate_tests == st_off.gate_tests and list(st_on.shape_tests) == list(st_off.shape_tests)
+    assert st_on.bvh_box_tests == st_off.bvh_box_tests
     scene.close()
     for seed in range(12):  # every shape type, nested groups with and without boxes; cameras outside and inside the shapes
         w, keep = su.random_world(seed, n_shapes=6 + seed % 12, groups=seed % 4)
@@ -1264,7 +1265,12 @@ def test_tile_cull_keeps_what_lies_behind_the_eye():
     behind_ball.common_attrs.transform = su.compose(su.translation(1.5, 2.5, -11), su.scaling(0.7, 0.7, 0.7))
     floor = st.Plane(st.default_attrs())
     floor.common_attrs.transform = su.translation(0, -1, 0)
-    w, keep = st.make_world([-4, 6, -5, 1], [1, 1, 1], spheres=[ball, behind_ball], planes=[floor], triangles=[tri])
+    crowd = []  # enough cheap shapes for spheres and triangles to get entries at all
+    for k in range(7):
+        pebble = st.Sphere(st.default_attrs())
+        pebble.common_attrs.transform = su.compose(su.translation(-3.0 + k, -0.7, 2.0 + 0.5 * k), su.scaling(0.3, 0.3, 0.3))
+        crowd.append(pebble)
+    w, keep = st.make_world([-4, 6, -5, 1], [1, 1, 1], spheres=[ball, behind_ball] + crowd, planes=[floor], triangles=[tri])
     cam = su.default_camera(128, 96, 1.0)  # from (0, 1.5, -7) towards the origin: the triangle and the second sphere are behind it
     scene = rta.Scene(w)
     on, st_on, off, st_off = _render_with_and_without_tile_cull(scene, cam)
@@ -1273,7 +1279,7 @@ def test_tile_cull_keeps_what_lies_behind_the_eye():
     ref, counts = o.render(cam, w)
     compare(on, ref, "glass behind the eye")
     # the triangle does change what the front sphere looks like: without it the canvas differs
-    w2, keep2 = st.make_world([-4, 6, -5, 1], [1, 1, 1], spheres=[ball, behind_ball], planes=[floor])
+    w2, keep2 = st.make_world([-4, 6, -5, 1], [1, 1, 1], spheres=[ball, behind_ball] + crowd, planes=[floor])
     scene2 = rta.Scene(w2)
     other, _ = scene2.render(cam)
     assert other.tobytes() != on.tobytes()
