@@ -661,8 +661,22 @@ template <bool GEN>
 TraceKernel twin_kernel(bool bvh) {
     return bvh ? k_trace_shade<kTabGlobal, GEN, true, false, true, false, false, true> : k_trace_shade<kTabGlobal, GEN, true, false, false, false, false, true>;
 }
+// The ray-generating kernels of frames with tile-culling entries (CULL).
+template <int TAB, bool... Flags>
+TraceKernel pick_cull() {
+    return k_trace_shade<TAB, true, Flags..., false, false, true>;
+}
+template <int TAB, bool... Flags, class... Rest>
+TraceKernel pick_cull(bool f, Rest... rest) {
+    return f ? pick_cull<TAB, Flags..., true>(rest...) : pick_cull<TAB, Flags..., false>(rest...);
+}
 template <bool GEN>
-TraceKernel trace_kernel(bool track, uint32_t tab, bool canon, bool bvh, bool stats = false) {
+TraceKernel trace_kernel(bool track, uint32_t tab, bool canon, bool bvh, bool stats = false, bool cull = false) {
+    if (GEN && cull) {
+        if (tab == (uint32_t)kTabAll) return pick_cull<kTabAll>(track, canon, bvh, stats);
+        if (tab == (uint32_t)kTabHit) return pick_cull<kTabHit>(track, canon, bvh, stats);
+        return pick_cull<kTabGlobal>(track, canon, bvh, stats);
+    }
     if (tab == (uint32_t)kTabAll) return pick_kernel<kTabAll, GEN>(track, canon, bvh, stats);
     if (tab == (uint32_t)kTabHit) return pick_kernel<kTabHit, GEN>(track, canon, bvh, stats);
     return pick_kernel<kTabGlobal, GEN>(track, canon, bvh, stats);
@@ -677,7 +691,7 @@ void launch_trace(const rtx_scene* s, const f32::Params& p, uint32_t level, uint
     const bool track = s->track_n1 && !(level == p.depth && s->finite_schlick);
     const TraceKernel k = (p.book && track) ? book_kernel<GEN>(p.has_bvh != 0)
                           : (p.twins && track) ? twin_kernel<GEN>(p.has_bvh != 0)
-                                               : trace_kernel<GEN>(track, p.tab_mode, p.canon != 0, p.has_bvh != 0, stats);
+                                               : trace_kernel<GEN>(track, p.tab_mode, p.canon != 0, p.has_bvh != 0, stats, p.n_cull != 0u);
     const bool stash = stash_enabled(GEN, p.book && track, p.twins && track && !p.book);
     const uint32_t lds = p.lds_bytes + (stash ? stash_bytes_per_block(track, (int)p.tab_mode) : 0u);
     hipLaunchKernelGGL(k, dim3(blocks), dim3(256), lds, st, p, level);
@@ -1448,7 +1462,7 @@ int render_impl_t(rtx_scene* s, const rtx_camera* cam, const rtx_opts* opts, flo
     p.compact_rows = compact ? 1u : 0u;
     p.canvas = d_rgb;
     // camera-ray tile culling: the plain walk only (a twin's test records that the ray reached it; the book walk keeps to itself)
-    if (!p.book && !p.twins) fill_cull(s, cam, plan, !(opts && opts->no_bvh), p);
+    if (!p.book && !p.twins && !kF64) fill_cull(s, cam, plan, !(opts && opts->no_bvh), p);  // (the f64 reporting kernels have no CULL variant)
 
     if (!fixed) HIP_TRY(hipEventRecord(s->ws[set0].ev_begin, st));
     // Canvas starts black (canvas.zig:23-25); rows never rendered stay black.  Every rendered
