@@ -302,8 +302,10 @@ uint32_t rtx_static_max_width(void);
  * (NULL / 0 = every visible device; an index may appear more than once, which is how a one-GPU box
  * rehearses the path).  A render cuts the frame into n_devices * chunks_per_gpu interleaved sets of
  * 16-row strips; one host thread per GPU takes sets from a shared counter until none is left
- * (chunks_per_gpu = 1: each GPU renders one set; > 1: a GPU that finishes early takes another —
- * dynamic stealing, where the reference's bands are static, src/camera.zig:88,99), renders each with
+ * (chunks_per_gpu = 1: each GPU renders one set; > 1: a GPU keeps up to min(chunks_per_gpu, 3) sets in
+ * flight, each on a stream, chunk canvas and work set (rtx_opts.work_set) of its own, and takes another
+ * only when one of them is done — dynamic stealing, where the reference's bands are static,
+ * src/camera.zig:88,99; with opts->lanes = 2 one set at a time), renders each with
  * the single-GPU pipeline and puts its rows in place:
  *   rtx_multi_render         into caller-owned HOST canvases (f32 and / or u8, either may be NULL),
  *                            every GPU copying over its own PCIe link;

@@ -6,7 +6,10 @@
 // ("chunks": chunk k of n holds the strips s with s % n == k, so every chunk sees the same mix of
 // cheap and expensive rows), one host thread per GPU takes chunks from a shared atomic counter until
 // none is left — with more chunks than GPUs that is dynamic stealing: a GPU that finishes early takes
-// the next chunk — renders each with the ordinary single-GPU pipeline (rtx_render_device, compact
+// the next chunk (a GPU keeps up to three chunks in flight, each on a stream, chunk canvas and work set of
+// its own — a chunk of a split frame fills little of a chip per launch, and its six level launches cannot
+// take less than their longest iterations — and claims another only when one of them is done) — renders
+// each with the ordinary single-GPU pipeline (rtx_render_device, compact
 // rows) and puts the rows where they belong: straight into the caller's host canvas over that GPU's
 // own PCIe link, or into a canvas on the first device with peer copies (one strided 2-D copy per chunk
 // and canvas over the peer's own xGMI link to the root: no ring, no staging; peer access is switched on
@@ -55,12 +58,15 @@ struct DeviceGuard {
     }
 };
 
+constexpr int kSlots = 3;  // chunks a GPU keeps in flight (rtx_opts.work_set has three sets)
+
 struct Gpu {
     int device = 0;
     rtx_scene* scene = nullptr;
-    hipStream_t stream = nullptr;
-    float* d_rgb = nullptr;     // compact rows of one chunk
-    uint8_t* d_rgb8 = nullptr;
+    hipStream_t stream[kSlots] = {};
+    hipEvent_t done[kSlots] = {};      // the slot's last chunk has been rendered and copied out
+    float* d_rgb[kSlots] = {};         // compact rows of one chunk
+    uint8_t* d_rgb8[kSlots] = {};
     size_t cap_rows = 0, cap_width = 0;
 };
 
@@ -80,14 +86,21 @@ uint32_t rendered_rows(const rtx_camera* cam, const rtx_opts* o) {
 
 int ensure_buffers(Gpu& g, size_t rows, size_t width) {
     if (rows <= g.cap_rows && width <= g.cap_width) return RTX_OK;
-    if (g.d_rgb) (void)hipFree(g.d_rgb);
-    if (g.d_rgb8) (void)hipFree(g.d_rgb8);
-    g.d_rgb = nullptr;
-    g.d_rgb8 = nullptr;
+    // (only ever grown by the GPU's own worker before its first chunk of a frame is queued, or after a smaller frame whose
+    // chunks rtx_multi_render has waited for: nothing is in flight on these buffers)
+    for (int k = 0; k < kSlots; ++k) {
+        if (g.d_rgb[k]) (void)hipFree(g.d_rgb[k]);
+        if (g.d_rgb8[k]) (void)hipFree(g.d_rgb8[k]);
+        g.d_rgb[k] = nullptr;
+        g.d_rgb8[k] = nullptr;
+    }
     g.cap_rows = g.cap_width = 0;
     const size_t n = (rows ? rows : 1) * width * 3;
-    hipError_t e = hipMalloc(&g.d_rgb, n * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc(&g.d_rgb8, n);
+    hipError_t e = hipSuccess;
+    for (int k = 0; k < kSlots && e == hipSuccess; ++k) {
+        e = hipMalloc(&g.d_rgb[k], n * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc(&g.d_rgb8[k], n);
+    }
     if (e != hipSuccess) return fail(RTX_E_HIP, std::string("hipMalloc (multi-GPU chunk canvas): ") + hipGetErrorString(e));
     g.cap_rows = rows;
     g.cap_width = width;
@@ -103,6 +116,8 @@ struct Job {
     uint8_t* rgb8_out;      // the same for the u8 canvas, may be NULL
     bool to_device;
     bool want_stats;
+    uint32_t slots;         // chunks a GPU keeps in flight (1 .. kSlots)
+    uint32_t max_rows;      // rows of the largest chunk: the chunk canvases are sized once per frame, before anything is queued
     std::atomic<uint32_t> next{0};
 };
 
@@ -143,7 +158,17 @@ void worker(Job* job, size_t gi, Result* res) {
     };
     hipError_t e = hipSetDevice(g.device);
     if (e != hipSuccess) return bail(RTX_E_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    int rc = ensure_buffers(g, job->max_rows, W);
+    if (rc) return bail(rc, rtx_last_error());
+    uint32_t taken = 0;  // chunks this GPU has queued
     for (;;) {
+        // A slot is free again when its last chunk is done: only then does this GPU claim another chunk, so that the
+        // chunks go to the GPUs that finish early (not to the threads that queue fastest).
+        const uint32_t slot = taken % job->slots;
+        if (taken >= job->slots) {
+            e = hipEventSynchronize(g.done[slot]);
+            if (e != hipSuccess) return bail(RTX_E_HIP, std::string("hipEventSynchronize: ") + hipGetErrorString(e));
+        }
         const uint32_t k = job->next.fetch_add(1u);
         if (k >= job->n_chunks) break;
         rtx_opts o = job->opts;
@@ -152,14 +177,15 @@ void worker(Job* job, size_t gi, Result* res) {
         o.strip_index = k;
         o.compact_rows = 1;
         o.profile = 0;
+        o.work_set = job->slots > 1 ? slot : 0u;
         uint32_t rows = 0;
-        int rc = rtx_rows_for(job->cam, &o, &rows);
+        rc = rtx_rows_for(job->cam, &o, &rows);
         if (rc) return bail(rc, rtx_last_error());
         if (rows == 0) continue;  // more chunks than strips
-        rc = ensure_buffers(g, rows, W);
-        if (rc) return bail(rc, rtx_last_error());
+        if (rows > g.cap_rows) return bail(RTX_E_INVALID, "chunk larger than the chunk canvas");
+        hipStream_t st_k = g.stream[slot];
         rtx_stats st;
-        rc = rtx_render_device(g.scene, job->cam, &o, g.d_rgb, job->rgb8_out ? g.d_rgb8 : nullptr, g.stream, job->want_stats ? &st : nullptr);
+        rc = rtx_render_device(g.scene, job->cam, &o, g.d_rgb[slot], job->rgb8_out ? g.d_rgb8[slot] : nullptr, st_k, job->want_stats ? &st : nullptr);
         if (rc) return bail(rc, rtx_last_error());
         if (job->want_stats) add_stats(res->stats, st);
         // The chunk's strips back to their rows: local strip j is global strip k + j * n_chunks, so the chunk is one
@@ -174,26 +200,31 @@ void worker(Job* job, size_t gi, Result* res) {
             const hipMemcpyKind kind = job->to_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
             hipError_t err = hipSuccess;
             if (full_strips)
-                err = hipMemcpy2DAsync(dst, (size_t)job->n_chunks * strip_elems * elt, src, strip_elems * elt, strip_elems * elt, full_strips, kind, g.stream);
+                err = hipMemcpy2DAsync(dst, (size_t)job->n_chunks * strip_elems * elt, src, strip_elems * elt, strip_elems * elt, full_strips, kind, st_k);
             if (err == hipSuccess && tail_rows)
                 err = hipMemcpyAsync(dst + (size_t)full_strips * job->n_chunks * strip_elems * elt, src + (size_t)full_strips * strip_elems * elt,
-                                     (size_t)tail_rows * W * 3 * elt, kind, g.stream);
+                                     (size_t)tail_rows * W * 3 * elt, kind, st_k);
             return err;
         };
         if (job->rgb_out) {
-            e = put(job->rgb_out, g.d_rgb, sizeof(float));
+            e = put(job->rgb_out, g.d_rgb[slot], sizeof(float));
             if (e != hipSuccess) return bail(RTX_E_HIP, std::string("canvas copy: ") + hipGetErrorString(e));
         }
         if (job->rgb8_out) {
-            e = put(job->rgb8_out, g.d_rgb8, 1);
+            e = put(job->rgb8_out, g.d_rgb8[slot], 1);
             if (e != hipSuccess) return bail(RTX_E_HIP, std::string("canvas copy: ") + hipGetErrorString(e));
         }
-        // The chunk buffers are reused by this GPU's next chunk: same stream, so the copies above
-        // are ordered before the next render.
+        // The slot's buffers and work set are reused by the chunk this GPU takes `slots` chunks later: same stream, so
+        // the copies above are ordered before that render.
+        e = hipEventRecord(g.done[slot], st_k);
+        if (e != hipSuccess) return bail(RTX_E_HIP, std::string("hipEventRecord: ") + hipGetErrorString(e));
         res->chunks++;
+        ++taken;
     }
-    e = hipStreamSynchronize(g.stream);
-    if (e != hipSuccess) return bail(RTX_E_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
+    for (int k = 0; k < kSlots; ++k) {
+        e = hipStreamSynchronize(g.stream[k]);
+        if (e != hipSuccess) return bail(RTX_E_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
+    }
 }
 
 int multi_render(rtx_multi* m, const rtx_camera* cam, const rtx_opts* opts, uint32_t chunks_per_gpu, float* rgb_out, uint8_t* rgb8_out,
@@ -220,14 +251,28 @@ int multi_render(rtx_multi* m, const rtx_camera* cam, const rtx_opts* opts, uint
     job.rgb8_out = rgb8_out;
     job.to_device = to_device;
     job.want_stats = stats != nullptr;
+    // two lanes (rtx_opts.lanes) use the scene's work sets themselves; a counted frame reads its statistics back chunk by chunk
+    job.slots = (job.opts.lanes > 1 || chunks_per_gpu < 2) ? 1u : (chunks_per_gpu < (uint32_t)kSlots ? chunks_per_gpu : (uint32_t)kSlots);
+    job.max_rows = 0;
+    for (uint32_t k = 0; k < job.n_chunks && k < 2u; ++k) {  // chunk 0 holds the most rows (and the partial last strip goes to a later one at most as large)
+        rtx_opts o = job.opts;
+        o.strip_rows = kStripRows;
+        o.strip_count = job.n_chunks;
+        o.strip_index = k;
+        o.compact_rows = 1;
+        uint32_t rows = 0;
+        rc = rtx_rows_for(cam, &o, &rows);
+        if (rc) return rc;
+        if (rows > job.max_rows) job.max_rows = rows;
+    }
     // Rows the reference never renders stay black (src/camera.zig:87-88, src/canvas.zig:23-25).
     const uint32_t W = cam->horizontal_size, H = cam->vertical_size, total = rendered_rows(cam, &job.opts);
     if (total < H) {
         const size_t off = (size_t)total * W * 3, count = (size_t)(H - total) * W * 3;
         if (to_device) {
             hipError_t e = hipSetDevice(m->gpus[0].device);
-            if (e == hipSuccess && rgb_out) e = hipMemsetAsync(rgb_out + off, 0, count * sizeof(float), m->gpus[0].stream);
-            if (e == hipSuccess && rgb8_out) e = hipMemsetAsync(rgb8_out + off, 0, count, m->gpus[0].stream);
+            if (e == hipSuccess && rgb_out) e = hipMemsetAsync(rgb_out + off, 0, count * sizeof(float), m->gpus[0].stream[0]);
+            if (e == hipSuccess && rgb8_out) e = hipMemsetAsync(rgb8_out + off, 0, count, m->gpus[0].stream[0]);
             if (e != hipSuccess) return fail(RTX_E_HIP, std::string("hipMemsetAsync: ") + hipGetErrorString(e));
         } else {
             if (rgb_out) std::memset(rgb_out + off, 0, count * sizeof(float));
@@ -277,7 +322,10 @@ int rtx_multi_create(const rtx_scene_desc* desc, const int* devices, uint32_t n_
         hipError_t e = hipSuccess;
         if (rc == RTX_OK) {
             e = hipSetDevice(g.device);
-            if (e == hipSuccess) e = hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking);
+            for (int k = 0; k < kSlots && e == hipSuccess; ++k) {
+                e = hipStreamCreateWithFlags(&g.stream[k], hipStreamNonBlocking);
+                if (e == hipSuccess) e = hipEventCreateWithFlags(&g.done[k], hipEventDisableTiming);
+            }
             if (e != hipSuccess) rc = fail(RTX_E_HIP, std::string("hipStreamCreateWithFlags: ") + hipGetErrorString(e));
         }
         if (rc) {
@@ -315,14 +363,17 @@ void rtx_multi_destroy(rtx_multi* m) {
     if (!m) return;
     DeviceGuard guard;
     for (Gpu& g : m->gpus) {
-        if (!g.scene && !g.stream && !g.d_rgb && !g.d_rgb8) continue;  // never set up (rtx_multi_create failed before it)
+        if (!g.scene && !g.stream[0] && !g.d_rgb[0]) continue;  // never set up (rtx_multi_create failed before it)
         (void)hipSetDevice(g.device);
-        if (g.stream) {
-            (void)hipStreamSynchronize(g.stream);
-            (void)hipStreamDestroy(g.stream);
+        for (int k = 0; k < kSlots; ++k) {
+            if (g.stream[k]) {
+                (void)hipStreamSynchronize(g.stream[k]);
+                (void)hipStreamDestroy(g.stream[k]);
+            }
+            if (g.done[k]) (void)hipEventDestroy(g.done[k]);
+            if (g.d_rgb[k]) (void)hipFree(g.d_rgb[k]);
+            if (g.d_rgb8[k]) (void)hipFree(g.d_rgb8[k]);
         }
-        if (g.d_rgb) (void)hipFree(g.d_rgb);
-        if (g.d_rgb8) (void)hipFree(g.d_rgb8);
         if (g.scene) rtx_scene_destroy(g.scene);
     }
     delete m;
