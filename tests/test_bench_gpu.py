@@ -43,3 +43,59 @@ def test_gpus_2_starts_its_own_ranks_and_rehearses_on_one_gpu():
     assert "equal the whole-frame render" in err
     d, err = _bench("--gpus", "2", "--steps", "4", "--warmup", "1", "--whole-frames")
     assert d["scaling"] == "weak" and "equal the whole-frame render" in err
+
+
+_RCCL_ONE_RANK = r"""
+import importlib, os, sys
+import torch
+import torch.distributed as dist
+sys.path.insert(0, %(root)r)
+tiling = importlib.import_module("ray-tracer_amd.tiling")
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=%(port)r)
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+H, W, SETS = 70, 48, 3
+ex = tiling.StripExchange(H, W, 16, frames=1, device=dev, sets=SETS)
+streams = [torch.cuda.Stream(device=dev) for _ in range(SETS)]
+local = [torch.zeros((1, ex.slot_rows, W, 3), dtype=torch.uint8, device=dev) for _ in range(SETS)]
+rows = tiling.rows_of_rank(H, 16, 1, 0)
+for k in range(7):  # bench.py's loop at N > 1: frame k on stream, canvas and exchange set k %% SETS
+    b = k %% SETS
+    with torch.cuda.stream(streams[b]):
+        ex.finish(b)
+        local[b].fill_(k + 1)
+        ex.submit(b, local[b])
+for b in range(SETS):
+    with torch.cuda.stream(streams[b]):
+        ex.finish(b)
+dist.barrier()
+torch.cuda.synchronize()
+want = {0: 7, 1: 5, 2: 6}  # the last frame that went through each set
+for b in range(SETS):
+    got = ex.fulls[b][0, : len(rows)]
+    assert bool((got == want[b]).all()), (b, int(got.min()), int(got.max()))
+    assert bool((ex.fulls[b][0, len(rows):] == 0).all())
+mine = torch.tensor([1.5, 2.5], dtype=torch.float64, device=dev)
+everyone = [torch.zeros_like(mine)]
+dist.all_gather(everyone, mine)
+t = mine.clone()
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+assert everyone[0].tolist() == [1.5, 2.5] and t.tolist() == [1.5, 2.5]
+dist.destroy_process_group()
+print("rccl one rank ok")
+"""
+
+
+def test_strip_exchange_over_rccl_with_one_rank():
+    """The collectives bench.py --gpus N issues (asynchronous gather per frame inside the frame's stream context, barrier,
+    all_gather / all_reduce of float64) through the RCCL backend itself, with the one rank a one-GPU box can give it: pins
+    the API use (device_id initialisation, gather on the nccl backend, waits on side streams), not the scaling."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = str(s.getsockname()[1])
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "-c", _RCCL_ONE_RANK % {"root": ROOT, "port": port}], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "rccl one rank ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
