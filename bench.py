@@ -496,7 +496,7 @@ def main():
 
         # --- BASELINE.json's other single-GPU configurations, a few frames each ---
         if not args.no_configs:
-            extra["configs"] = other_configs(rta, torch, dev, stream, obj_text)
+            extra["configs"] = other_configs(rta, torch, dev, stream, obj_text, in_flight=F)
 
     if rank == 0:
         launches = prof.launches_trace_shade
@@ -585,31 +585,48 @@ def main():
         dist.destroy_process_group()
 
 
-def other_configs(rta, torch, dev, stream, obj_text, frames=10):
-    """Frame ms and Mrays/s of BASELINE.json's other single-GPU configurations (device-resident canvas)."""
+def other_configs(rta, torch, dev, stream, obj_text, frames=20, in_flight=2):
+    """Frame ms and Mrays/s of BASELINE.json's other single-GPU configurations (device-resident canvases): a frame loop like the
+    headline's, `in_flight` frames in flight (frame k on work set and stream k % in_flight), and the same frames one at a time."""
     rows = []
+    streams = [torch.cuda.Stream(device=dev) for _ in range(in_flight)]
 
     def measure(label, config, world, cam, w, h):
         scene = rta.Scene(world, device=dev.index)
         fcam = rta.flatten_camera(cam)
-        rgb = torch.zeros((h, w, 3), dtype=torch.float32, device=dev)
-        rgb8 = torch.zeros((h, w, 3), dtype=torch.uint8, device=dev)
-        st = scene.render_device(fcam, rgb.data_ptr(), rgb8.data_ptr(), stream=stream, want_stats=True)
+        rgb = [torch.zeros((h, w, 3), dtype=torch.float32, device=dev) for _ in range(in_flight)]
+        rgb8 = [torch.zeros((h, w, 3), dtype=torch.uint8, device=dev) for _ in range(in_flight)]
+        st = scene.render_device(fcam, rgb[0].data_ptr(), rgb8[0].data_ptr(), stream=stream, want_stats=True)
         for _ in range(2):
-            scene.render_device(fcam, rgb.data_ptr(), rgb8.data_ptr(), stream=stream)
+            scene.render_device(fcam, rgb[0].data_ptr(), rgb8[0].data_ptr(), stream=stream)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(frames):
-            scene.render_device(fcam, rgb.data_ptr(), rgb8.data_ptr(), stream=stream)
+            scene.render_device(fcam, rgb[0].data_ptr(), rgb8[0].data_ptr(), stream=stream)
+        torch.cuda.synchronize()
+        ms_alone = (time.perf_counter() - t0) / frames * 1e3
+
+        def frame(k):
+            b = k % in_flight
+            scene.render_device(fcam, rgb[b].data_ptr(), rgb8[b].data_ptr(), stream=streams[b].cuda_stream, work_set=b)
+
+        for k in range(2 * in_flight):
+            frame(k)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(frames):
+            frame(k)
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / frames * 1e3
+        assert all(torch.equal(rgb8[0], x) for x in rgb8[1:]), "%s: the canvases of the frame slots differ" % label
         flops = trace_shade_flops(st)
         rows.append({"config": config, "scene": label, "size": "%dx%d" % (w, h), "shapes": scene.n_shapes, "rays_per_frame": st.rays_total,
-                     "frame_ms": ms, "mrays_per_s": st.rays_total / ms / 1e3, "flops_per_frame": flops,
-                     # the frame's algorithmic flops over the WHOLE frame time (level kernels + combine + quantise), so a lower
-                     # bound on the dominant kernel's own fraction
-                     "kernel": "k_trace_shade", "achieved_tflops_whole_frame": flops / (ms * 1e-3) / 1e12,
-                     "frac": flops / (ms * 1e-3) / 1e12 / VALU_PEAK_FMA_TFLOPS})
+                     "frame_ms": ms, "frames_in_flight": in_flight, "frame_ms_one_at_a_time": ms_alone,
+                     "mrays_per_s": st.rays_total / ms / 1e3, "flops_per_frame": flops,
+                     # the frame's algorithmic flops over the WHOLE frame time (level kernels + combine + quantise) of the frame
+                     # running alone, so a lower bound on the dominant kernel's own fraction
+                     "kernel": "k_trace_shade", "achieved_tflops_whole_frame": flops / (ms_alone * 1e-3) / 1e12,
+                     "frac": flops / (ms_alone * 1e-3) / 1e12 / VALU_PEAK_FMA_TFLOPS})
         scene.close()
         del rgb, rgb8
 

@@ -20,7 +20,9 @@ print("full: %.4f ms  %.0f Mrays/s  events avg %.4f  frac %.4f  d2h %.3f  f64 %.
     f["f64_report"]["frame_ms"], f["f64_report"]["frac_of_fp64_vector_peak"]))
 print("cpu", f["cpu_baseline"]["value"], f["cpu_baseline_all_threads"]["value"])
 for c in f.get("configs", []):
-    print("  %-32s %-10s %.3f ms %6.0f Mrays/s" % (c["scene"], c["size"], c["frame_ms"], c["mrays_per_s"]))
+    print("  %-32s %-10s %.3f ms (%s in flight; one at a time %s) %6.0f Mrays/s" % (
+        c["scene"], c["size"], c["frame_ms"], c.get("frames_in_flight", 1),
+        "%.3f ms" % c["frame_ms_one_at_a_time"] if c.get("frame_ms_one_at_a_time") else "-", c["mrays_per_s"]))
 rows = list(csv.DictReader(open("profiles/%s_bench_kernel_stats.csv" % tag)))
 tot = n = 0
 for row in rows[:6]:
