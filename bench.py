@@ -363,8 +363,9 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         # Per-launch HIP events break the back-to-back dispatch (and force one lane), so only every
-        # EVENT_EVERY-th timed step carries them.
-        frame(k, not args.no_events and k % EVENT_EVERY == EVENT_EVERY // 2)
+        # EVENT_EVERY-th timed step carries them — counted back from the last one, which has to drain the frames in
+        # flight anyway (and so that a run of fewer steps still has one).
+        frame(k, not args.no_events and (args.steps - 1 - k) % EVENT_EVERY == 0)
     fence()
     dt = time.perf_counter() - t0
     prof = scene.profile_collect()
@@ -502,7 +503,7 @@ def main():
         launches = prof.launches_trace_shade
         avg_ms = prof.ms_trace_shade / max(launches, 1)
         flops_frame = trace_shade_flops(stats)
-        profiled_steps = len(range(EVENT_EVERY // 2, args.steps, EVENT_EVERY)) if not args.no_events else 0
+        profiled_steps = (args.steps + EVENT_EVERY - 1) // EVENT_EVERY if not args.no_events else 0
         flops_per_launch = flops_frame * profiled_steps / max(launches, 1)
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         traffic, traffic_src, traffic_build = measured_traffic() if n == 1 else (None, None, None)  # the PMC pass is of whole frames
